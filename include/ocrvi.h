@@ -1,0 +1,134 @@
+/* libocrvi -- C ABI of the MI355X-native (gfx950) DBNet++ / SVTRv2 / CTC inference hot path.
+ *
+ * The reference (ZenHKD/ocr-vi-invoice) is pure Python and has no FFI; the hot path sits behind two
+ * torch.nn.Module forward APIs.  Each entry point below names the reference interface it replaces.
+ * Plain pointers and sizes only -- no torch types.  All device pointers are HIP device memory on the
+ * handle's device.  Every *_forward only enqueues work on `stream` (a hipStream_t passed as void*): no
+ * allocation, no host synchronisation, so calls are graph-capturable.  The caller owns inputs, outputs
+ * and workspace; a handle owns its (repacked) weights only.  Handles are per-device and not thread-safe.
+ *
+ * Errors: every function returns 0 (OCRVI_OK) or a negative code and never aborts the process;
+ * ocrvi_last_error() returns a thread-local message for the last failing call.
+ */
+#ifndef OCRVI_H
+#define OCRVI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OCRVI_OK 0
+#define OCRVI_EINVAL (-1) /* bad shape / alignment / argument (reference: ATen shape errors, svtrv2.py:425 assert) */
+#define OCRVI_EHIP (-2)   /* a HIP runtime call failed; message carries hipGetErrorString */
+#define OCRVI_ENOMEM (-3) /* workspace too small */
+#define OCRVI_EBLOB (-4)  /* weight blob malformed or a tensor is missing / has the wrong shape */
+
+/* Arithmetic type the MFMA kernels compute in (accumulation is always fp32). */
+typedef enum { OCRVI_F32 = 0, OCRVI_BF16 = 1, OCRVI_F16 = 2 } ocrvi_dtype;
+
+const char* ocrvi_last_error(void);
+/* ABI version of this header (bumped on any signature change). */
+int ocrvi_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Detection: replaces DBNetPP(backbone='resnet50', dcn=True).eval() -- model/det/dbnet.py:6-17
+ * (ResNet-50 + DCNv2 backbone model/det/backbone.py:8-60, dcn.py:41-59; FPN+ASF neck neck.py:26-79;
+ * DB head head.py:32-48).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct ocrvi_det ocrvi_det;
+
+typedef struct {
+    int32_t dtype;   /* ocrvi_dtype */
+    float k;         /* DB step-function steepness, head.py:6,28-30 (reference default 50) */
+    int32_t max_batch;  /* largest N a forward call will see (sizes nothing; validated only) */
+    int32_t reserved[5];
+} ocrvi_det_cfg;
+
+/* `blob` = host bytes produced by ocr_vi_invoice_amd.weights.pack_blob(fold_det(state_dict)): BN already
+ * folded (eval-mode running stats), standard OIHW fp32 tensors.  Replaces load_state_dict + .to(device) +
+ * .eval() of load_detection_model (src/pipeline/pipeline2.py:43-54). */
+int ocrvi_det_create(int device, const void* blob, size_t blob_bytes, const ocrvi_det_cfg* cfg, ocrvi_det** out);
+void ocrvi_det_destroy(ocrvi_det* h);
+/* Bytes of scratch device memory one forward of shape (N,3,H,W) needs. */
+int ocrvi_det_workspace_bytes(const ocrvi_det* h, int N, int H, int W, size_t* bytes);
+/* Replaces DBNetPP.forward (dbnet.py:13-17).  x: float32 NCHW [N,3,H,W], H and W multiples of 32
+ * (pipeline2.py:33-40 guarantees it).  Outputs are float32 [N,1,H,W]; `binary` is required, the other four
+ * dict entries of head.py:42-48 may be NULL (then not written; the arithmetic that produces them is still
+ * the same two-branch head). */
+int ocrvi_det_forward(ocrvi_det* h, const float* x, int N, int H, int W,
+                      float* binary, float* thresh, float* thresh_binary, float* bin_logits, float* thresh_logits,
+                      void* workspace, size_t workspace_bytes, void* stream);
+/* Test hook: copies of intermediate features as float32 NCHW (c2..c5 backbone.py:56-60, fused neck.py:79).
+ * Any pointer may be NULL.  Must follow a forward on the same workspace and stream. */
+int ocrvi_det_debug_features(ocrvi_det* h, int N, int H, int W, float* c2, float* c3, float* c4, float* c5,
+                             float* fused, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Recognition: replaces SVTRv2(variant).eval() -- model/rec2/svtrv2.py:410-569 (inference graph; the
+ * SGM branch, svtrv2.py:252-385, is training-only and not built).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct ocrvi_rec ocrvi_rec;
+
+typedef struct {
+    int32_t dtype;        /* ocrvi_dtype */
+    int32_t dims[3];      /* VARIANTS[..]['dims']       svtrv2.py:391-407 */
+    int32_t num_blocks[3];/* VARIANTS[..]['num_blocks'] */
+    int32_t num_local[3]; /* VARIANTS[..]['num_local']  (first num_local blocks of a stage are LocalMixing) */
+    int32_t num_classes;  /* tokenizer.num_classes = 232 (tokenizer.py:21) */
+    int32_t blank_id;     /* 0 (tokenizer.py:14) */
+    int32_t reserved[4];
+} ocrvi_rec_cfg;
+
+/* `blob` = pack_blob(fold_rec(state_dict, variant)).  Replaces load_recognition_model
+ * (src/pipeline/pipeline2.py:72-82). */
+int ocrvi_rec_create(int device, const void* blob, size_t blob_bytes, const ocrvi_rec_cfg* cfg, ocrvi_rec** out);
+void ocrvi_rec_destroy(ocrvi_rec* h);
+int ocrvi_rec_workspace_bytes(const ocrvi_rec* h, int B, int H, int W, size_t* bytes);
+/* Replaces SVTRv2.forward(x, targets=None) (svtrv2.py:503-536) fused with decode_probs' device half
+ * (svtrv2.py:555-566).  x: float32 NCHW [B,3,H,W], H % 16 == 0 and W % 4 == 0, T = W/4.
+ *   log_probs [T,B,num_classes] float32 (may be NULL)
+ *   argmax_ids [B,T] int32: per-step argmax over classes, first index wins ties (may be NULL)
+ *   ids [B,T] int32: greedy CTC path after collapsing repeats and dropping `blank_id`, padded with -1
+ *   lens [B] int32: number of valid entries of each ids row
+ * ids/lens may both be NULL.  Mapping ids -> text (which also drops pad id 1, tokenizer.py:73) is host work. */
+int ocrvi_rec_forward(ocrvi_rec* h, const float* x, int B, int H, int W,
+                      float* log_probs, int32_t* argmax_ids, int32_t* ids, int32_t* lens,
+                      void* workspace, size_t workspace_bytes, void* stream);
+/* Test hook: float32 copies of backbone_norm output [B, H/16*W/4, D] (svtrv2.py:500) and FRM output
+ * [B, W/4, D] (svtrv2.py:247).  Either may be NULL.  Must follow a forward on the same workspace/stream. */
+int ocrvi_rec_debug_features(ocrvi_rec* h, int B, int H, int W, float* backbone_norm, float* frm,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
+/* Standalone greedy CTC decode of caller-supplied log-probs: replaces SVTRv2.decode_probs' tensor half
+ * (svtrv2.py:555-566).  log_probs [T,B,C] float32 on device. */
+int ocrvi_ctc_greedy(int device, const float* log_probs, int T, int B, int C, int blank_id,
+                     int32_t* argmax_ids, int32_t* ids, int32_t* lens, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Kernel-level test/bench hooks (same kernels the models launch; used by tests/ and bench.py for
+ * per-kernel parity and roofline timing).
+ * ------------------------------------------------------------------------------------------------ */
+/* Modulated deformable 3x3 conv, pad 1, dil 1 (torchvision.ops.deform_conv2d as called at dcn.py:48-57) with
+ * a fused per-channel bias (+ optional ReLU) epilogue.  x float32 NCHW [N,C,H,W]; offset [N,18,Ho,Wo];
+ * mask [N,9,Ho,Wo] (already sigmoided); weight float32 host [Co,C,3,3]; bias float32 host [Co] or NULL;
+ * out float32 NCHW [N,Co,Ho,Wo].  Allocates and synchronises internally (test hook, not graph-capturable). */
+int ocrvi_test_deform_conv(int device, int dtype, const float* x, const float* offset, const float* mask,
+                           const float* weight_host, const float* bias_host, int N, int C, int H, int W, int Co,
+                           int stride, int relu, float* out, int iters, float* avg_ms);
+/* Plain conv2d (groups, stride (sh,sw), square kernel 1 or 3, pad = k/2) + bias + activation
+ * (0 none, 1 ReLU, 2 exact GELU).  Same conventions as above. */
+int ocrvi_test_conv(int device, int dtype, const float* x, const float* weight_host, const float* bias_host,
+                    int N, int C, int H, int W, int Co, int ksize, int sh, int sw, int groups, int act, float* out,
+                    int iters, float* avg_ms);
+/* Multi-head self-attention on a packed qkv tensor [B, N, 3*heads*32] float32 (layout of
+ * qkv.reshape(B,N,3,heads,32), svtrv2.py:80) -> out [B, N, heads*32] float32 (svtrv2.py:82-85). */
+int ocrvi_test_attention(int device, int dtype, const float* qkv, int B, int N, int heads, float* out, int iters,
+                         float* avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OCRVI_H */

@@ -1,0 +1,159 @@
+// Kernel-level hooks of the C ABI (include/ocrvi.h, "test/bench hooks"): run ONE production kernel on
+// caller-supplied float32 NCHW device tensors.  They allocate scratch, convert layouts, time with HIP events on
+// their own stream, and synchronise -- test infrastructure around the same kernels the model graphs launch.
+#include <memory>
+
+#include "model.h"
+
+using namespace ocrvi;
+
+namespace {
+template <typename T>
+__global__ void nchw_f32_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y, int N, int C, int HW) {
+    const size_t total = (size_t)N * C * HW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const size_t t = i / C;
+        const int p = (int)(t % HW), n = (int)(t / HW);
+        y[i] = from_f32<T>(x[((size_t)n * C + c) * HW + p]);
+    }
+}
+int to_nhwc(int dt, const float* x, void* y, int N, int C, int HW, hipStream_t s) {
+    const size_t total = (size_t)N * C * HW;
+    const int grid = (int)std::min<size_t>((total + 255) / 256, 16384);
+    switch (dt) {
+        case OCRVI_F32: hipLaunchKernelGGL(nchw_f32_to_nhwc_kernel<float>, dim3(grid), dim3(256), 0, s, x, (float*)y, N, C, HW); break;
+        case OCRVI_BF16: hipLaunchKernelGGL(nchw_f32_to_nhwc_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, x, (bf16_t*)y, N, C, HW); break;
+        case OCRVI_F16: hipLaunchKernelGGL(nchw_f32_to_nhwc_kernel<f16_t>, dim3(grid), dim3(256), 0, s, x, (f16_t*)y, N, C, HW); break;
+        default: set_error("unknown dtype %d", dt); return OCRVI_EINVAL;
+    }
+    OCRVI_HIP(hipGetLastError());
+    return OCRVI_OK;
+}
+// [N][18][P] offsets + [N][9][P] masks -> [N*P][32] rows (the layout the offset conv's epilogue writes)
+__global__ void pack_offsets_kernel(const float* __restrict__ off, const float* __restrict__ mask, float* __restrict__ o, int N, int P) {
+    const size_t total = (size_t)N * P * 32;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i & 31);
+        const size_t m = i >> 5;
+        const int p = (int)(m % P), n = (int)(m / P);
+        float v = 0.f;
+        if (c < 18) v = off[((size_t)n * 18 + c) * P + p];
+        else if (c < 27) v = mask[((size_t)n * 9 + (c - 18)) * P + p];
+        o[i] = v;
+    }
+}
+struct Scratch {
+    std::vector<void*> p;
+    hipStream_t s = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~Scratch() {
+        for (void* q : p) (void)hipFree(q);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        if (s) (void)hipStreamDestroy(s);
+    }
+    int alloc(size_t bytes, void** out) {
+        OCRVI_HIP(hipMalloc(out, bytes ? bytes : 16));
+        p.push_back(*out);
+        return OCRVI_OK;
+    }
+    int init() {
+        OCRVI_HIP(hipStreamCreate(&s));
+        OCRVI_HIP(hipEventCreate(&e0));
+        OCRVI_HIP(hipEventCreate(&e1));
+        return OCRVI_OK;
+    }
+};
+template <typename F>
+int timed(Scratch& sc, int iters, float* avg_ms, F&& launch) {
+    OCRVI_TRY(launch());  // warm-up / the run whose output is checked
+    if (iters > 0 && avg_ms) {
+        OCRVI_HIP(hipEventRecord(sc.e0, sc.s));
+        for (int i = 0; i < iters; ++i) OCRVI_TRY(launch());
+        OCRVI_HIP(hipEventRecord(sc.e1, sc.s));
+        OCRVI_HIP(hipEventSynchronize(sc.e1));
+        float ms = 0.f;
+        OCRVI_HIP(hipEventElapsedTime(&ms, sc.e0, sc.e1));
+        *avg_ms = ms / iters;
+    }
+    return OCRVI_OK;
+}
+}  // namespace
+
+extern "C" int ocrvi_test_deform_conv(int device, int dtype, const float* x, const float* offset, const float* mask,
+                                      const float* weight_host, const float* bias_host, int N, int C, int H, int W, int Co, int stride,
+                                      int relu, float* out, int iters, float* avg_ms) {
+    OCRVI_CHECK(x && offset && mask && weight_host && out && (stride == 1 || stride == 2), OCRVI_EINVAL, "test_deform_conv: bad argument");
+    OCRVI_HIP(hipSetDevice(device));
+    Scratch sc;
+    OCRVI_TRY(sc.init());
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    DeviceStore st;
+    ConvLayer L;
+    PackedConv pc = pack_conv(weight_host, bias_host, Co, C, 3, 3, 1, AM_DCN, dtype);
+    OCRVI_TRY(upload_packed(st, pc, AM_DCN, &L));
+    void *xn = nullptr, *yn = nullptr, *offs = nullptr;
+    OCRVI_TRY(sc.alloc((size_t)N * H * W * C * dtype_size(dtype), &xn));
+    OCRVI_TRY(sc.alloc((size_t)N * Ho * Wo * Co * dtype_size(dtype), &yn));
+    OCRVI_TRY(sc.alloc((size_t)N * Ho * Wo * 32 * 4, &offs));
+    OCRVI_TRY(to_nhwc(dtype, x, xn, N, C, H * W, sc.s));
+    hipLaunchKernelGGL(pack_offsets_kernel, dim3(1024), dim3(256), 0, sc.s, offset, mask, (float*)offs, N, Ho * Wo);
+    OCRVI_HIP(hipGetLastError());
+    Runner r(dtype, sc.s, (void*)256, 0);
+    Tensor tx; tx.p = xn; tx.n = N; tx.h = H; tx.w = W; tx.c = C;
+    Tensor ty; ty.p = yn; ty.n = N; ty.h = Ho; ty.w = Wo; ty.c = Co;
+    ConvOpts o;
+    o.sh = o.sw = stride; o.pad = 1; o.act = relu ? ACT_RELU : ACT_NONE; o.offs = (const float*)offs;
+    OCRVI_TRY(timed(sc, iters, avg_ms, [&]() { return conv(r, L, tx, ty, o); }));
+    OCRVI_TRY(k_nhwc_to_nchw_f32(dtype, yn, out, N, Ho, Wo, Co, Co, 0, sc.s));
+    OCRVI_HIP(hipStreamSynchronize(sc.s));
+    return OCRVI_OK;
+}
+
+extern "C" int ocrvi_test_conv(int device, int dtype, const float* x, const float* weight_host, const float* bias_host, int N, int C,
+                               int H, int W, int Co, int ksize, int sh, int sw, int groups, int act, float* out, int iters, float* avg_ms) {
+    OCRVI_CHECK(x && weight_host && out && (ksize == 1 || ksize == 3) && groups >= 1 && C % groups == 0 && Co % groups == 0, OCRVI_EINVAL,
+                "test_conv: bad argument");
+    OCRVI_HIP(hipSetDevice(device));
+    Scratch sc;
+    OCRVI_TRY(sc.init());
+    const int pad = ksize / 2;
+    const int Ho = (H + 2 * pad - ksize) / sh + 1, Wo = (W + 2 * pad - ksize) / sw + 1;
+    const int amode = ksize == 1 ? AM_CONV1 : AM_CONV3;
+    DeviceStore st;
+    ConvLayer L;
+    PackedConv pc = pack_conv(weight_host, bias_host, Co, C / groups, ksize, ksize, groups, amode, dtype);
+    OCRVI_TRY(upload_packed(st, pc, amode, &L));
+    void *xn = nullptr, *yn = nullptr;
+    OCRVI_TRY(sc.alloc((size_t)N * H * W * C * dtype_size(dtype), &xn));
+    OCRVI_TRY(sc.alloc((size_t)N * Ho * Wo * Co * dtype_size(dtype), &yn));
+    OCRVI_TRY(to_nhwc(dtype, x, xn, N, C, H * W, sc.s));
+    Runner r(dtype, sc.s, (void*)256, 0);
+    Tensor tx; tx.p = xn; tx.n = N; tx.h = H; tx.w = W; tx.c = C;
+    Tensor ty; ty.p = yn; ty.n = N; ty.h = Ho; ty.w = Wo; ty.c = Co;
+    ConvOpts o;
+    o.sh = sh; o.sw = sw; o.pad = pad; o.act = act;
+    OCRVI_TRY(timed(sc, iters, avg_ms, [&]() { return conv(r, L, tx, ty, o); }));
+    OCRVI_TRY(k_nhwc_to_nchw_f32(dtype, yn, out, N, Ho, Wo, Co, Co, 0, sc.s));
+    OCRVI_HIP(hipStreamSynchronize(sc.s));
+    return OCRVI_OK;
+}
+
+extern "C" int ocrvi_test_attention(int device, int dtype, const float* qkv, int B, int N, int heads, float* out, int iters, float* avg_ms) {
+    OCRVI_CHECK(qkv && out && B > 0 && N > 0 && heads > 0, OCRVI_EINVAL, "test_attention: bad argument");
+    OCRVI_HIP(hipSetDevice(device));
+    Scratch sc;
+    OCRVI_TRY(sc.init());
+    const int D = heads * 32;
+    const size_t nin = (size_t)B * N * 3 * D, nout = (size_t)B * N * D;
+    void *q = nullptr, *o = nullptr;
+    OCRVI_TRY(sc.alloc(nin * dtype_size(dtype), &q));
+    OCRVI_TRY(sc.alloc(nout * dtype_size(dtype), &o));
+    OCRVI_TRY(k_cast_from_f32(dtype, qkv, q, nin, sc.s));
+    OCRVI_TRY(timed(sc, iters, avg_ms, [&]() { return k_attention(dtype, q, o, B, N, heads, sc.s); }));
+    // [B*N][D] T -> float32 (same layout): a C=1 "NHWC -> NCHW" copy is a plain cast
+    OCRVI_TRY(k_nhwc_to_nchw_f32(dtype, o, out, 1, 1, (int)nout, 1, 1, 0, sc.s));
+    OCRVI_HIP(hipStreamSynchronize(sc.s));
+    return OCRVI_OK;
+}

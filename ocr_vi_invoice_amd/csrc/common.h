@@ -1,0 +1,182 @@
+// Shared host/device helpers for libocrvi (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "../../include/ocrvi.h"
+
+namespace ocrvi {
+
+// ---------------------------------------------------------------- errors
+void set_error(const char* fmt, ...);
+#define OCRVI_HIP(call)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            ::ocrvi::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return OCRVI_EHIP;                                                                   \
+        }                                                                                        \
+    } while (0)
+#define OCRVI_CHECK(cond, code, ...)            \
+    do {                                        \
+        if (!(cond)) {                          \
+            ::ocrvi::set_error(__VA_ARGS__);    \
+            return (code);                      \
+        }                                       \
+    } while (0)
+#define OCRVI_TRY(expr)          \
+    do {                         \
+        int rc_ = (expr);        \
+        if (rc_ != OCRVI_OK) return rc_; \
+    } while (0)
+
+// ---------------------------------------------------------------- element types
+typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <typename T> struct TypeInfo;
+template <> struct TypeInfo<float> { static constexpr int dtype = OCRVI_F32; static constexpr int EPC = 4; };
+template <> struct TypeInfo<bf16_t> { static constexpr int dtype = OCRVI_BF16; static constexpr int EPC = 8; };
+template <> struct TypeInfo<f16_t> { static constexpr int dtype = OCRVI_F16; static constexpr int EPC = 8; };
+
+static inline size_t dtype_size(int dt) { return dt == OCRVI_F32 ? 4 : 2; }
+
+template <typename T> __host__ __device__ inline T from_f32(float v) { return (T)v; }
+template <typename T> __host__ __device__ inline float to_f32(T v) { return (float)v; }
+
+// A 16-byte chunk of T elements <-> floats.
+template <typename T> struct Chunk;  // EPC elements
+template <> struct Chunk<float> {
+    static constexpr int N = 4;
+    __device__ static inline void unpack(const uint4& u, float* f) {
+        f[0] = __uint_as_float(u.x); f[1] = __uint_as_float(u.y); f[2] = __uint_as_float(u.z); f[3] = __uint_as_float(u.w);
+    }
+    __device__ static inline uint4 pack(const float* f) {
+        return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+    }
+};
+template <> struct Chunk<bf16_t> {
+    static constexpr int N = 8;
+    __device__ static inline void unpack(const uint4& u, float* f) {
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[2 * i] = __uint_as_float(w[i] << 16);
+            f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+    }
+    __device__ static inline uint4 pack(const float* f) {
+        union { bf16_t h[8]; uint4 u; } r;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r.h[i] = (bf16_t)f[i];
+        return r.u;
+    }
+};
+template <> struct Chunk<f16_t> {
+    static constexpr int N = 8;
+    __device__ static inline void unpack(const uint4& u, float* f) {
+        union { uint4 u; f16_t h[8]; } r;
+        r.u = u;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = (float)r.h[i];
+    }
+    __device__ static inline uint4 pack(const float* f) {
+        union { f16_t h[8]; uint4 u; } r;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r.h[i] = (f16_t)f[i];
+        return r.u;
+    }
+};
+
+// ---------------------------------------------------------------- MFMA wrappers (16x16 output tile)
+// A fragment is the 32 bytes lane (r = lane&15, g = lane>>4) reads from row r of a [rows][128 B] LDS tile
+// at byte offset 32*g.  The K order inside a 128-byte K-step is therefore permuted identically for both
+// operands, which a dot product does not care about.
+template <typename T> struct Mma;
+template <> struct Mma<float> {
+    __device__ static inline void run(const uint4 (&a)[2], const uint4 (&b)[2], f32x4& c) {
+        const uint32_t aw[8] = {a[0].x, a[0].y, a[0].z, a[0].w, a[1].x, a[1].y, a[1].z, a[1].w};
+        const uint32_t bw[8] = {b[0].x, b[0].y, b[0].z, b[0].w, b[1].x, b[1].y, b[1].z, b[1].w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(aw[j]), __uint_as_float(bw[j]), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<bf16_t> {
+    __device__ static inline void run(const uint4 (&a)[2], const uint4 (&b)[2], f32x4& c) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[s]), __builtin_bit_cast(bf16x8, b[s]), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<f16_t> {
+    __device__ static inline void run(const uint4 (&a)[2], const uint4 (&b)[2], f32x4& c) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[s]), __builtin_bit_cast(f16x8, b[s]), c, 0, 0, 0);
+    }
+};
+
+// Swizzle for [rows][128 B] LDS tiles read as (row = base + lane&15, chunks 2g, 2g+1) with ds_read_b128:
+// conflict-free under the gfx950 lane-group / 64-bank rule (checked by simulation).
+__device__ __forceinline__ int swz128(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 2); }
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// XCD-aware block remap (cdna_hip_programming.md T1, bijective form): consecutive logical tiles land on one XCD.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---------------------------------------------------------------- workspace arena
+// Bump allocator over the caller's workspace.  In planning mode (base == nullptr) it only measures.
+struct Arena {
+    char* base = nullptr;
+    size_t cap = 0, off = 0, peak = 0;
+    bool overflow = false;
+    Arena(void* p, size_t bytes) : base((char*)p), cap(bytes) {}
+    bool planning() const { return base == nullptr; }
+    void* alloc(size_t bytes) {
+        off = align_up(off, 256);
+        size_t o = off;
+        off += bytes;
+        if (off > peak) peak = off;
+        if (planning()) return (void*)(uintptr_t)256;  // never dereferenced
+        if (off > cap) { overflow = true; return nullptr; }
+        return base + o;
+    }
+    size_t mark() const { return off; }
+    void release(size_t m) { off = m; }
+};
+
+// ---------------------------------------------------------------- weight blob (host)
+struct BlobTensor {
+    std::string name;
+    int ndim = 0;
+    int dims[4] = {1, 1, 1, 1};
+    const float* data = nullptr;
+    size_t count = 0;
+};
+struct Blob {
+    std::vector<BlobTensor> tensors;
+    int parse(const void* blob, size_t bytes);
+    const BlobTensor* find(const std::string& name) const;
+    // fetch with shape check; dims<0 = wildcard
+    int get(const std::string& name, int d0, int d1, int d2, int d3, const BlobTensor** out) const;
+};
+
+// Host fp32 -> T conversion into a byte buffer.
+void convert_to_dtype(const float* src, size_t n, int dtype, void* dst);
+
+}  // namespace ocrvi

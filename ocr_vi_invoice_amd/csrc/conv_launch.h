@@ -1,0 +1,84 @@
+// launch_conv<T>: host-side validation + tile dispatch for conv_gemm_kernel.  Included by conv_{f32,bf16,f16}.hip
+// (one translation unit per dtype so they compile in parallel).
+#pragma once
+#include "conv_gemm.h"
+
+namespace ocrvi {
+
+template <typename T, int AMODE, int BM, int BN, int WM, int WN>
+static int launch_tile(const ConvParams& p, hipStream_t stream) {
+    constexpr int smem = 2 * (BM + BN) * 128;
+    auto kern = conv_gemm_kernel<T, AMODE, BM, BN, WM, WN>;
+    static bool attr_done = false;  // one-time opt-in for > 48 KiB dynamic LDS
+    if (!attr_done) {
+        OCRVI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_done = true;
+    }
+    const int mtiles = cdiv(p.M, BM), ntiles = p.Np / BN;
+    dim3 grid(mtiles * ntiles, p.groups);
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, p);
+    OCRVI_HIP(hipGetLastError());
+    return OCRVI_OK;
+}
+
+template <typename T, int AMODE>
+static int launch_mode(const ConvParams& p, hipStream_t stream) {
+    const int bn = conv_bn_for(p.N_g);
+    OCRVI_CHECK(p.Np % bn == 0 && p.Np >= p.N_g, OCRVI_EINVAL, "conv: Np=%d not a multiple of BN=%d / < N_g=%d", p.Np, bn, p.N_g);
+    if constexpr (AMODE == AM_DCN) {
+        OCRVI_CHECK(bn == 128, OCRVI_EINVAL, "dcn: needs N_g > 64 (got %d)", p.N_g);
+        return launch_tile<T, AMODE, 128, 128, 2, 2>(p, stream);
+    } else if constexpr (AMODE == AM_ROWS) {
+        OCRVI_CHECK(bn <= 64, OCRVI_EINVAL, "rows-mode stem conv: N_g=%d > 64 unsupported", p.N_g);
+        if (bn == 64) return launch_tile<T, AMODE, 128, 64, 2, 2>(p, stream);
+        return launch_tile<T, AMODE, 128, 32, 4, 1>(p, stream);
+    } else {
+        if (bn == 128) return launch_tile<T, AMODE, 128, 128, 2, 2>(p, stream);
+        if (bn == 64) return launch_tile<T, AMODE, 128, 64, 2, 2>(p, stream);
+        return launch_tile<T, AMODE, 128, 32, 4, 1>(p, stream);
+    }
+}
+
+template <typename T>
+int launch_conv(const ConvParams& p, int amode, hipStream_t stream) {
+    constexpr int EPC = TypeInfo<T>::EPC, BKE = 8 * EPC;
+    OCRVI_CHECK(p.x && p.w && p.out, OCRVI_EINVAL, "conv: null operand");
+    OCRVI_CHECK(p.M > 0 && p.M == p.n_img * p.OH * p.OW, OCRVI_EINVAL, "conv: M=%d != %d*%d*%d", p.M, p.n_img, p.OH, p.OW);
+    OCRVI_CHECK(p.Kp > 0 && p.Kp % BKE == 0, OCRVI_EINVAL, "conv: Kp=%d not a multiple of %d", p.Kp, BKE);
+    OCRVI_CHECK(p.groups >= 1 && p.N_g >= 1, OCRVI_EINVAL, "conv: bad groups/N");
+    OCRVI_CHECK((size_t)p.M * (size_t)(p.ldo > 32 ? p.ldo : 32) < ((size_t)1 << 40), OCRVI_EINVAL, "conv: output too large");
+    if (p.store_mode != ST_DCN_OFFS) {
+        OCRVI_CHECK(p.N_g % 4 == 0 && p.ldo % 4 == 0 && p.out_coff % 4 == 0, OCRVI_EINVAL,
+                    "conv: N_g=%d ldo=%d coff=%d must be multiples of 4", p.N_g, p.ldo, p.out_coff);
+    } else {
+        OCRVI_CHECK(p.bias && p.N_g <= 32 && p.groups == 1, OCRVI_EINVAL, "dcn offset conv: needs bias, N<=32");
+    }
+    if (p.res_mode != RES_NONE) OCRVI_CHECK(p.res && p.ldr % 4 == 0, OCRVI_EINVAL, "conv: residual missing / ldr%%4");
+    if (p.res_mode == RES_UP2) OCRVI_CHECK(p.OH % 2 == 0 && p.OW % 2 == 0, OCRVI_EINVAL, "conv: RES_UP2 needs even OH/OW");
+    if (p.store_mode == ST_SHUFFLE2)
+        OCRVI_CHECK(p.shuffle_co > 0 && p.shuffle_co % 4 == 0 && p.N_g == 4 * p.shuffle_co, OCRVI_EINVAL, "conv: bad pixel-shuffle N");
+    if (amode == AM_ROWS) {
+        OCRVI_CHECK(p.groups == 1 && p.Hp >= (p.OH - 1) * p.SH + p.KH && p.Wp >= (p.OW - 1) * p.SW + 8 && p.Wp % 2 == 0 &&
+                        p.Kp >= p.KH * 32 && (p.SW * 4) % EPC == 0,
+                    OCRVI_EINVAL, "rows-mode conv: padded input %dx%d too small for %dx%d out", p.Hp, p.Wp, p.OH, p.OW);
+        return launch_mode<T, AM_ROWS>(p, stream);
+    }
+    OCRVI_CHECK(p.Cin_g % EPC == 0 && p.Cin % EPC == 0 && p.cin_off % EPC == 0 && p.cin_off + p.groups * p.Cin_g <= p.Cin,
+                OCRVI_EINVAL, "conv: channel counts Cin=%d Cin_g=%d off=%d must be multiples of %d", p.Cin, p.Cin_g, p.cin_off, EPC);
+    const int ks = amode == AM_CONV1 ? 1 : 3;
+    OCRVI_CHECK(p.Kp >= ks * ks * p.Cin_g, OCRVI_EINVAL, "conv: Kp=%d < %d", p.Kp, ks * ks * p.Cin_g);
+    OCRVI_CHECK((p.OH - 1) * p.SH - p.PH + ks - 1 < p.H + ks && (p.OW - 1) * p.SW - p.PW + ks - 1 < p.W + ks, OCRVI_EINVAL,
+                "conv: output %dx%d inconsistent with input %dx%d", p.OH, p.OW, p.H, p.W);
+    switch (amode) {
+        case AM_CONV1: return launch_mode<T, AM_CONV1>(p, stream);
+        case AM_CONV3: return launch_mode<T, AM_CONV3>(p, stream);
+        case AM_DCN:
+            OCRVI_CHECK(p.offs && p.Cin_g % BKE == 0 && p.groups == 1, OCRVI_EINVAL, "dcn: needs offsets and Cin %% %d == 0", BKE);
+            return launch_mode<T, AM_DCN>(p, stream);
+        default: break;
+    }
+    set_error("conv: unknown A mode %d", amode);
+    return OCRVI_EINVAL;
+}
+
+}  // namespace ocrvi

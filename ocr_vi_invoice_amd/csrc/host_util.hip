@@ -1,0 +1,163 @@
+// Host utilities: error string, blob parsing, dtype conversion, weight packing, dtype dispatch.
+#include <stdarg.h>
+#include <string.h>
+
+#include "conv_gemm.h"
+
+namespace ocrvi {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+const char* last_error_cstr() { return g_err; }
+
+// ------------------------------------------------------------------ blob
+#pragma pack(push, 1)
+struct BlobEntry {
+    char name[64];
+    uint32_t ndim;
+    uint32_t dims[4];
+    uint64_t offset;
+    uint64_t count;
+};
+#pragma pack(pop)
+static_assert(sizeof(BlobEntry) == 100, "entry layout");
+
+int Blob::parse(const void* blob, size_t bytes) {
+    OCRVI_CHECK(blob && bytes >= 16 && memcmp(blob, "OCRVIW1\0", 8) == 0, OCRVI_EBLOB, "weight blob: bad magic / too short");
+    uint32_t n;
+    memcpy(&n, (const char*)blob + 8, 4);
+    OCRVI_CHECK(16 + (size_t)n * sizeof(BlobEntry) <= bytes, OCRVI_EBLOB, "weight blob: truncated table");
+    tensors.resize(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        BlobEntry e;
+        memcpy(&e, (const char*)blob + 16 + (size_t)i * sizeof(BlobEntry), sizeof(e));
+        e.name[63] = 0;
+        OCRVI_CHECK(e.ndim <= 4 && e.offset % 4 == 0 && e.offset + e.count * 4 <= bytes, OCRVI_EBLOB,
+                    "weight blob: tensor %s out of bounds", e.name);
+        size_t prod = 1;
+        for (uint32_t d = 0; d < e.ndim; ++d) prod *= e.dims[d];
+        OCRVI_CHECK(prod == e.count, OCRVI_EBLOB, "weight blob: tensor %s count mismatch", e.name);
+        BlobTensor& t = tensors[i];
+        t.name = e.name;
+        t.ndim = (int)e.ndim;
+        for (int d = 0; d < 4; ++d) t.dims[d] = d < (int)e.ndim ? (int)e.dims[d] : 1;
+        t.data = (const float*)((const char*)blob + e.offset);
+        t.count = e.count;
+    }
+    return OCRVI_OK;
+}
+const BlobTensor* Blob::find(const std::string& name) const {
+    for (const auto& t : tensors)
+        if (t.name == name) return &t;
+    return nullptr;
+}
+int Blob::get(const std::string& name, int d0, int d1, int d2, int d3, const BlobTensor** out) const {
+    const BlobTensor* t = find(name);
+    OCRVI_CHECK(t, OCRVI_EBLOB, "weight blob: missing tensor '%s'", name.c_str());
+    const int want[4] = {d0, d1, d2, d3};
+    for (int d = 0; d < 4; ++d) {
+        const int have = d < t->ndim ? t->dims[d] : 1;
+        OCRVI_CHECK(want[d] < 0 || have == (want[d] == 0 ? 1 : want[d]), OCRVI_EBLOB,
+                    "weight blob: tensor '%s' dim %d is %d, expected %d", name.c_str(), d, have, want[d]);
+    }
+    *out = t;
+    return OCRVI_OK;
+}
+
+// ------------------------------------------------------------------ dtype conversion (host, round-to-nearest-even)
+static inline uint16_t f32_to_bf16_bits(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1);
+    return (uint16_t)(u >> 16);
+}
+void convert_to_dtype(const float* src, size_t n, int dtype, void* dst) {
+    if (dtype == OCRVI_F32) {
+        memcpy(dst, src, n * 4);
+    } else if (dtype == OCRVI_BF16) {
+        uint16_t* d = (uint16_t*)dst;
+        for (size_t i = 0; i < n; ++i) d[i] = f32_to_bf16_bits(src[i]);
+    } else {
+        _Float16* d = (_Float16*)dst;
+        for (size_t i = 0; i < n; ++i) d[i] = (_Float16)src[i];
+    }
+}
+
+// ------------------------------------------------------------------ weight packing
+static PackedConv finish_pack(const std::vector<float>& wt, int groups, int Np, int Kp, int dtype) {
+    PackedConv pc;
+    pc.bytes.resize(wt.size() * dtype_size(dtype));
+    convert_to_dtype(wt.data(), wt.size(), dtype, pc.bytes.data());
+    pc.Np = Np;
+    pc.Kp = Kp;
+    pc.groups = groups;
+    return pc;
+}
+
+PackedConv pack_conv(const float* w, const float* bias, int cout, int cin_g, int kh, int kw, int groups, int amode, int dtype) {
+    const int bke = conv_bke(dtype);
+    const int n_g = cout / groups;
+    const int bn = conv_bn_for(n_g);
+    const int Np = cdiv(n_g, bn) * bn;
+    int Kp;
+    if (amode == AM_ROWS) Kp = cdiv(kh * 32, bke) * bke;
+    else Kp = cdiv(kh * kw * cin_g, bke) * bke;
+    std::vector<float> wt((size_t)groups * Np * Kp, 0.f);
+    for (int g = 0; g < groups; ++g)
+        for (int n = 0; n < n_g; ++n) {
+            const float* src = w + (size_t)(g * n_g + n) * cin_g * kh * kw;
+            float* dst = wt.data() + ((size_t)g * Np + n) * Kp;
+            for (int c = 0; c < cin_g; ++c)
+                for (int r = 0; r < kh; ++r)
+                    for (int s = 0; s < kw; ++s) {
+                        const float v = src[(c * kh + r) * kw + s];
+                        if (amode == AM_ROWS) dst[r * 32 + s * 4 + c] = v;          // [filter row][pixel s][ch c of 4]
+                        else dst[(r * kw + s) * cin_g + c] = v;                      // [tap][cin]
+                    }
+        }
+    PackedConv pc = finish_pack(wt, groups, Np, Kp, dtype);
+    pc.N_g = n_g;
+    pc.Cin_g = cin_g;
+    pc.KH = kh;
+    if (bias) pc.bias.assign(bias, bias + cout);
+    return pc;
+}
+
+PackedConv pack_deconv2(const float* w, const float* bias, int cin, int cout, int dtype) {
+    const int bke = conv_bke(dtype);
+    const int n_g = 4 * cout;
+    const int bn = conv_bn_for(n_g);
+    const int Np = cdiv(n_g, bn) * bn, Kp = cdiv(cin, bke) * bke;
+    std::vector<float> wt((size_t)Np * Kp, 0.f);
+    for (int ci = 0; ci < cin; ++ci)
+        for (int co = 0; co < cout; ++co)
+            for (int ab = 0; ab < 4; ++ab) wt[(size_t)(ab * cout + co) * Kp + ci] = w[((size_t)ci * cout + co) * 4 + ab];
+    PackedConv pc = finish_pack(wt, 1, Np, Kp, dtype);
+    pc.N_g = n_g;
+    pc.Cin_g = cin;
+    pc.bias.resize(n_g);
+    for (int ab = 0; ab < 4; ++ab)
+        for (int co = 0; co < cout; ++co) pc.bias[ab * cout + co] = bias ? bias[co] : 0.f;
+    return pc;
+}
+
+int launch_conv_dt(int dtype, const ConvParams& p, int amode, hipStream_t stream) {
+    switch (dtype) {
+        case OCRVI_F32: return launch_conv<float>(p, amode, stream);
+        case OCRVI_BF16: return launch_conv<bf16_t>(p, amode, stream);
+        case OCRVI_F16: return launch_conv<f16_t>(p, amode, stream);
+    }
+    set_error("unknown dtype %d", dtype);
+    return OCRVI_EINVAL;
+}
+
+}  // namespace ocrvi
+
+extern "C" const char* ocrvi_last_error(void) { return ocrvi::last_error_cstr(); }
+extern "C" int ocrvi_abi_version(void) { return 1; }

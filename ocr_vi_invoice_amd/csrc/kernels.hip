@@ -1,0 +1,497 @@
+// Memory-bound kernels of the hot path: layout conversion, max-pool, LayerNorm, FRM column attention, ASF,
+// DB head tail, CTC log-softmax / argmax / collapse.  wave64 reductions, 8..16-byte vector accesses.
+#include "kernels.h"
+
+namespace ocrvi {
+
+#define DISPATCH_DT(dt, CALL)                                        \
+    switch (dt) {                                                    \
+        case OCRVI_F32: { using T = float; CALL; break; }            \
+        case OCRVI_BF16: { using T = bf16_t; CALL; break; }          \
+        case OCRVI_F16: { using T = f16_t; CALL; break; }            \
+        default: set_error("unknown dtype %d", dt); return OCRVI_EINVAL; \
+    }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// 4 consecutive T elements <-> float[4]
+template <typename T> __device__ __forceinline__ void load4(const T* p, float* f) {
+    if constexpr (sizeof(T) == 4) {
+        const float4 v = *(const float4*)p;
+        f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+    } else {
+        union { uint2 u; T h[4]; } r;
+        r.u = *(const uint2*)p;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] = (float)r.h[i];
+    }
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, const float* f) {
+    if constexpr (sizeof(T) == 4) {
+        *(float4*)p = make_float4(f[0], f[1], f[2], f[3]);
+    } else {
+        union { uint2 u; T h[4]; } r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r.h[i] = (T)f[i];
+        *(uint2*)p = r.u;
+    }
+}
+
+// ------------------------------------------------------------------ NCHW3 f32 -> padded NHWC4 T
+template <typename T>
+__global__ void nchw3_to_nhwc4_pad_kernel(const float* __restrict__ x, T* __restrict__ y, int N, int H, int W, int pt, int pl, int Hp, int Wp) {
+    const size_t total = (size_t)N * Hp * Wp;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int xp = (int)(i % Wp);
+        const size_t t = i / Wp;
+        const int yp = (int)(t % Hp), n = (int)(t / Hp);
+        const int yy = yp - pt, xx = xp - pl;
+        float f[4] = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
+            const size_t plane = (size_t)H * W, o = (size_t)n * 3 * plane + (size_t)yy * W + xx;
+            f[0] = x[o]; f[1] = x[o + plane]; f[2] = x[o + 2 * plane];
+        }
+        store4<T>(y + i * 4, f);
+    }
+}
+int k_nchw3_to_nhwc4_pad(int dtype, const float* x, void* y, int N, int H, int W, int pad_t, int pad_l, int Hp, int Wp, hipStream_t s) {
+    OCRVI_CHECK(x && y && N > 0 && Hp >= H + pad_t && Wp >= W + pad_l, OCRVI_EINVAL, "nhwc4 pad: bad shape");
+    const size_t total = (size_t)N * Hp * Wp;
+    const int grid = (int)std::min<size_t>((total + 255) / 256, 8192);
+    DISPATCH_DT(dtype, hipLaunchKernelGGL(nchw3_to_nhwc4_pad_kernel<T>, dim3(grid), dim3(256), 0, s, x, (T*)y, N, H, W, pad_t, pad_l, Hp, Wp));
+    OCRVI_HIP(hipGetLastError());
+    return OCRVI_OK;
+}
+
+// ------------------------------------------------------------------ maxpool 3x3 s2 p1, NHWC
+template <typename T>
+__global__ void maxpool3x3s2_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C, int OH, int OW) {
+    constexpr int EPC = TypeInfo<T>::EPC;
+    const int cch = C / EPC;
+    const size_t total = (size_t)N * OH * OW * cch;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % cch);
+        size_t t = i / cch;
+        const int ow = (int)(t % OW); t /= OW;
+        const int oh = (int)(t % OH);
+        const int n = (int)(t / OH);
+        float m[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) m[e] = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int ih = oh * 2 - 1 + r;
+            if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int iw = ow * 2 - 1 + q;
+                if ((unsigned)iw >= (unsigned)W) continue;
+                float f[EPC];
+                Chunk<T>::unpack(*(const uint4*)(x + (((size_t)n * H + ih) * W + iw) * C + cc * EPC), f);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) m[e] = fmaxf(m[e], f[e]);
+            }
+        }
+        *(uint4*)(y + (((size_t)n * OH + oh) * OW + ow) * C + cc * EPC) = Chunk<T>::pack(m);
+    }
+}
+int k_maxpool3x3s2(int dtype, const void* x, void* y, int N, int H, int W, int C, hipStream_t s) {
+    OCRVI_CHECK(x && y && C % 8 == 0 && H >= 2 && W >= 2, OCRVI_EINVAL, "maxpool: bad shape C=%d", C);
+    const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    const size_t total = (size_t)N * OH * OW * (C / (dtype == OCRVI_F32 ? 4 : 8));
+    const int grid = (int)std::min<size_t>((total + 255) / 256, 16384);
+    DISPATCH_DT(dtype, hipLaunchKernelGGL(maxpool3x3s2_kernel<T>, dim3(grid), dim3(256), 0, s, (const T*)x, (T*)y, N, H, W, C, OH, OW));
+    OCRVI_HIP(hipGetLastError());
+    return OCRVI_OK;
+}
+
+// ------------------------------------------------------------------ LayerNorm: one wave per row
+template <typename TI, typename TO>
+__global__ void layernorm_kernel(const TI* __restrict__ x, TO* __restrict__ out, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, int rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const TI* xr = x + (size_t)row * D;
+    constexpr int MAXV = 4;  // D <= 1024
+    float v[MAXV][4];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) {
+            load4<TI>(xr + c, v[i]);
+            sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        }
+    }
+    const float mean = wave_sum(sum) / (float)D;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; sq += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)D + 1e-5f);
+    TO* orow = out + (size_t)row * D;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) {
+            const float4 g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
+            float o[4] = {(v[i][0] - mean) * rstd * g.x + b.x, (v[i][1] - mean) * rstd * g.y + b.y,
+                          (v[i][2] - mean) * rstd * g.z + b.z, (v[i][3] - mean) * rstd * g.w + b.w};
+            store4<TO>(orow + c, o);
+        }
+    }
+}
+int k_layernorm(int dtype, const void* x, int x_f32, void* out, int out_f32, const float* gamma, const float* beta, int rows, int D,
+                hipStream_t s) {
+    OCRVI_CHECK(x && out && gamma && beta && rows > 0 && D % 4 == 0 && D <= 1024, OCRVI_EINVAL, "layernorm: bad shape rows=%d D=%d", rows, D);
+    const dim3 grid(cdiv(rows, 4)), block(256);
+    DISPATCH_DT(dtype, {
+        if (x_f32 && out_f32) hipLaunchKernelGGL((layernorm_kernel<float, float>), grid, block, 0, s, (const float*)x, (float*)out, gamma, beta, rows, D);
+        else if (x_f32) hipLaunchKernelGGL((layernorm_kernel<float, T>), grid, block, 0, s, (const float*)x, (T*)out, gamma, beta, rows, D);
+        else if (out_f32) hipLaunchKernelGGL((layernorm_kernel<T, float>), grid, block, 0, s, (const T*)x, (float*)out, gamma, beta, rows, D);
+        else hipLaunchKernelGGL((layernorm_kernel<T, T>), grid, block, 0, s, (const T*)x, (T*)out, gamma, beta, rows, D);
+    });
+    OCRVI_HIP(hipGetLastError());
+    return OCRVI_OK;
+}
+
+// ------------------------------------------------------------------ casts / layout taps
+template <typename T>
+__global__ void cast_from_f32_kernel(const float* __restrict__ x, T* __restrict__ y, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float f[4];
+        load4<float>(x + i * 4, f);
+        store4<T>(y + i * 4, f);
+    }
+}
+int k_cast_from_f32(int dtype, const float* x, void* y, size_t n, hipStream_t s) {
+    OCRVI_CHECK(x && y && n % 4 == 0, OCRVI_EINVAL, "cast: n %% 4 != 0");
+    const int grid = (int)std::min<size_t>((n / 4 + 255) / 256, 8192);
+    DISPATCH_DT(dtype, hipLaunchKernelGGL(cast_from_f32_kernel<T>, dim3(std::max(grid, 1)), dim3(256), 0, s, x, (T*)y, n / 4));
+    OCRVI_HIP(hipGetLastError());
+    return OCRVI_OK;
+}
+
+template <typename T>
+__global__ void nhwc_to_nchw_f32_kernel(const T* __restrict__ x, float* __restrict__ y, int N, int HW, int C, int ld, int coff) {
+    // 32x32 tile transpose through LDS so both sides are coalesced
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: ty 0..7
+    for (int r = ty; r < 32; r += 8) {
+        const int p = p0 + r, c = c0 + tx;
+        tile[r][tx] = (p < HW && c < C) ? to_f32<T>(x[((size_t)n * HW + p) * ld + coff + c]) : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, p = p0 + tx;
+        if (p < HW && c < C) y[((size_t)n * C + c) * HW + p] = tile[tx][r];
+    }
+}
+int k_nhwc_to_nchw_f32(int dtype, const void* x, float* y, int N, int H, int W, int C, int ld, int coff, hipStream_t s) {
+    OCRVI_CHECK(x && y && N > 0 && N < 65536, OCRVI_EINVAL, "nhwc->nchw: bad shape");
+    const int HW = H * W;
+    dim3 grid(cdiv(HW, 32), cdiv(C, 32), N);
+    DISPATCH_DT(dtype, hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel<T>, grid, dim3(256), 0, s, (const T*)x, y, N, HW, C, ld, coff));
+    OCRVI_HIP(hipGetLastError());
+    return OCRVI_OK;
+}
+
+// ------------------------------------------------------------------ FRM vertical cross-attention (H keys per column, head_dim 32)
+// One half-wave (32 lanes = head_dim) per (column, head): lane d holds q[d], k_h[d], v_h[d].
+template <typename T>
+__global__ void frm_vertical_kernel(const T* __restrict__ kv, const float* __restrict__ vq, T* __restrict__ out, int B, int H, int W, int D) {
+    const int heads = D >> 5;
+    const size_t total = (size_t)B * W * heads;
+    const int d = threadIdx.x & 31;
+    const size_t item = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    if (item >= total) return;  // whole 32-lane group exits together
+    const int hd = (int)(item % heads);
+    const size_t col = item / heads;  // b*W + w
+    const int b = (int)(col / W), w = (int)(col % W);
+    const float q = vq[hd * 32 + d];
+    const float scale = 0.17677669529663687f;  // 32^-0.5
+    float mx = -INFINITY, sc[8], vv[8];
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+        if (h >= H) break;
+        const size_t tok = ((size_t)b * H + h) * W + w;
+        const float kk = to_f32<T>(kv[tok * 2 * D + hd * 32 + d]);
+        vv[h] = to_f32<T>(kv[tok * 2 * D + D + hd * 32 + d]);
+        float s = q * kk;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        sc[h] = s * scale;
+        mx = fmaxf(mx, sc[h]);
+    }
+    float den = 0.f, acc = 0.f;
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+        if (h >= H) break;
+        const float p = __expf(sc[h] - mx);
+        den += p;
+        acc += p * vv[h];
+    }
+    out[col * D + hd * 32 + d] = from_f32<T>(acc / den);
+}
+int k_frm_vertical(int dtype, const void* kv, const float* vq, void* out, int B, int H, int W, int D, hipStream_t s) {
+    OCRVI_CHECK(kv && vq && out && D % 32 == 0 && H >= 1 && H <= 8, OCRVI_EINVAL, "frm vertical: D=%d H=%d unsupported", D, H);
+    const size_t threads = (size_t)B * W * (D / 32) * 32;
+    DISPATCH_DT(dtype, hipLaunchKernelGGL(frm_vertical_kernel<T>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, (const T*)kv, vq, (T*)out, B, H, W, D));
+    OCRVI_HIP(hipGetLastError());
+    return OCRVI_OK;
+}
+
+// ------------------------------------------------------------------ ASF (adaptive scale fusion), one wave per pixel, 4 ch per lane
+template <typename T>
+__global__ __launch_bounds__(256) void asf_kernel(const T* __restrict__ p2, const T* __restrict__ p3, const T* __restrict__ p4,
+                                                  const T* __restrict__ p5, const float* __restrict__ w, const float* __restrict__ bias,
+                                                  T* __restrict__ out, int N, int H, int W) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    // attention weights for this lane's 4 channels: wreg[score i][level l][e]
+    float wreg[4][4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            const float4 t = *(const float4*)(w + i * 1024 + l * 256 + lane * 4);
+            wreg[i][l][0] = t.x; wreg[i][l][1] = t.y; wreg[i][l][2] = t.z; wreg[i][l][3] = t.w;
+        }
+    const T* lev[4] = {p2, p3, p4, p5};
+    const size_t total = (size_t)N * H * W;
+    for (size_t pix = wave; pix < total; pix += nwaves) {
+        const int x = (int)(pix % W);
+        const size_t t = pix / W;
+        const int y = (int)(t % H), n = (int)(t / H);
+        float f[4][4];
+        load4<T>(p2 + pix * 256 + lane * 4, f[0]);
+#pragma unroll
+        for (int l = 1; l < 4; ++l) {
+            const int Hl = H >> l, Wl = W >> l;
+            // F.interpolate(bilinear, align_corners=True): src = dst * (in-1)/(out-1)  (neck.py:65)
+            const float sh = H > 1 ? (float)(Hl - 1) / (float)(H - 1) : 0.f, sw = W > 1 ? (float)(Wl - 1) / (float)(W - 1) : 0.f;
+            const float fy = sh * (float)y, fx = sw * (float)x;
+            const int y0 = (int)fy, x0 = (int)fx;
+            const int y1 = y0 + (y0 < Hl - 1 ? 1 : 0), x1 = x0 + (x0 < Wl - 1 ? 1 : 0);
+            const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+            const T* base = lev[l] + (size_t)n * Hl * Wl * 256 + lane * 4;
+            float a[4], b[4], c[4], d[4];
+            load4<T>(base + ((size_t)y0 * Wl + x0) * 256, a);
+            load4<T>(base + ((size_t)y0 * Wl + x1) * 256, b);
+            load4<T>(base + ((size_t)y1 * Wl + x0) * 256, c);
+            load4<T>(base + ((size_t)y1 * Wl + x1) * 256, d);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) f[l][e] = hy * (hx * a[e] + lx * b[e]) + ly * (hx * c[e] + lx * d[e]);
+        }
+        float sc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float a = 0.f;
+#pragma unroll
+            for (int l = 0; l < 4; ++l)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a = fmaf(wreg[i][l][e], f[l][e], a);
+            sc[i] = wave_sum(a) + bias[i];
+        }
+        const float mx = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+        float den = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { sc[i] = __expf(sc[i] - mx); den += sc[i]; }
+        const float inv = 1.f / den;
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (f[0][e] * sc[0] + f[1][e] * sc[1] + f[2][e] * sc[2] + f[3][e] * sc[3]) * inv;
+        store4<T>(out + pix * 256 + lane * 4, o);
+    }
+}
+int k_asf(int dtype, const void* p2, const void* p3, const void* p4, const void* p5, const float* w, const float* b, void* out, int N,
+          int H, int W, hipStream_t s) {
+    OCRVI_CHECK(p2 && p3 && p4 && p5 && w && b && out && H % 8 == 0 && W % 8 == 0, OCRVI_EINVAL, "asf: bad shape %dx%d", H, W);
+    const size_t total = (size_t)N * H * W;
+    const int grid = (int)std::min<size_t>((total + 3) / 4, 256 * 8);
+    DISPATCH_DT(dtype, hipLaunchKernelGGL(asf_kernel<T>, dim3(grid), dim3(256), 0, s, (const T*)p2, (const T*)p3, (const T*)p4, (const T*)p5, w, b, (T*)out, N, H, W));
+    OCRVI_HIP(hipGetLastError());
+    return OCRVI_OK;
+}
+
+// ------------------------------------------------------------------ DB head tail: deconv2 (64->1, 2x2 s2) x2 branches + sigmoid + step
+template <typename T>
+__global__ __launch_bounds__(256) void db_tail_kernel(const T* __restrict__ y, const float* __restrict__ w2, const float* __restrict__ b2, float k,
+                                                      float* __restrict__ binary, float* __restrict__ thresh, float* __restrict__ tbin,
+                                                      float* __restrict__ blog, float* __restrict__ tlog, int N, int H2, int W2) {
+    __shared__ float ws[2 * 64 * 4];
+    for (int i = threadIdx.x; i < 512; i += blockDim.x) ws[i] = w2[i];
+    __syncthreads();
+    constexpr int EPC = TypeInfo<T>::EPC;
+    const size_t total = (size_t)N * H2 * W2;
+    const int OW = 2 * W2;
+    for (size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pix < total; pix += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(pix % W2);
+        const size_t t = pix / W2;
+        const int yy = (int)(t % H2), n = (int)(t / H2);
+        float lg[2][4];
+#pragma unroll
+        for (int br = 0; br < 2; ++br) {
+            float a[4] = {b2[br], b2[br], b2[br], b2[br]};
+#pragma unroll
+            for (int cc = 0; cc < 64 / EPC; ++cc) {
+                float f[EPC];
+                Chunk<T>::unpack(*(const uint4*)(y + pix * 128 + br * 64 + cc * EPC), f);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const float4 wv = *(const float4*)(ws + (br * 64 + cc * EPC + e) * 4);
+                    a[0] = fmaf(f[e], wv.x, a[0]); a[1] = fmaf(f[e], wv.y, a[1]);
+                    a[2] = fmaf(f[e], wv.z, a[2]); a[3] = fmaf(f[e], wv.w, a[3]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) lg[br][q] = a[q];
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const size_t o = ((size_t)n * (2 * H2) + 2 * yy + a) * OW + 2 * x;
+            const float l0 = lg[0][a * 2], l1 = lg[0][a * 2 + 1], t0 = lg[1][a * 2], t1 = lg[1][a * 2 + 1];
+            const float pb0 = 1.f / (1.f + expf(-l0)), pb1 = 1.f / (1.f + expf(-l1));
+            const float pt0 = 1.f / (1.f + expf(-t0)), pt1 = 1.f / (1.f + expf(-t1));
+            *(float2*)(binary + o) = make_float2(pb0, pb1);
+            if (thresh) *(float2*)(thresh + o) = make_float2(pt0, pt1);
+            if (tbin) *(float2*)(tbin + o) = make_float2(1.f / (1.f + expf(-k * (pb0 - pt0))), 1.f / (1.f + expf(-k * (pb1 - pt1))));
+            if (blog) *(float2*)(blog + o) = make_float2(l0, l1);
+            if (tlog) *(float2*)(tlog + o) = make_float2(t0, t1);
+        }
+    }
+}
+int k_db_tail(int dtype, const void* y, const float* w2, const float* b2, float k, float* binary, float* thresh, float* thresh_binary,
+              float* bin_logits, float* thresh_logits, int N, int H2, int W2, hipStream_t s) {
+    OCRVI_CHECK(y && w2 && b2 && binary && N > 0, OCRVI_EINVAL, "db tail: null operand");
+    const size_t total = (size_t)N * H2 * W2;
+    const int grid = (int)std::min<size_t>((total + 255) / 256, 256 * 16);
+    DISPATCH_DT(dtype, hipLaunchKernelGGL(db_tail_kernel<T>, dim3(grid), dim3(256), 0, s, (const T*)y, w2, b2, k, binary, thresh, thresh_binary, bin_logits, thresh_logits, N, H2, W2));
+    OCRVI_HIP(hipGetLastError());
+    return OCRVI_OK;
+}
+
+// ------------------------------------------------------------------ CTC: log-softmax + argmax (one wave per (b,t) row), collapse
+__device__ __forceinline__ void wave_argmax(float& v, int& idx) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(v, o);
+        const int oi = __shfl_xor(idx, o);
+        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    }
+}
+
+__global__ void ctc_logsoftmax_argmax_kernel(const float* __restrict__ logits, int ld, float* __restrict__ log_probs,
+                                             int32_t* __restrict__ argmax_ids, int B, int T, int C) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // b*T + t
+    if (row >= B * T) return;
+    const int b = row / T, t = row % T;
+    const float* x = logits + (size_t)row * ld;
+    constexpr int MAXV = 16;  // C <= 1024
+    float v[MAXV];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = i * 64 + lane;
+        v[i] = c < C ? x[c] : -INFINITY;
+        mx = fmaxf(mx, v[i]);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+        if (i * 64 + lane < C) sum += expf(v[i] - mx);
+    const float lse = logf(wave_sum(sum));
+    // argmax over the log-probabilities themselves (svtrv2.py:555 takes argmax of log_softmax output); first index wins ties
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = i * 64 + lane;
+        if (c < C) {
+            const float lp = (v[i] - mx) - lse;
+            if (log_probs) log_probs[((size_t)t * B + b) * C + c] = lp;
+            if (lp > best) { best = lp; bi = c; }
+        }
+    }
+    wave_argmax(best, bi);
+    if (argmax_ids && lane == 0) argmax_ids[(size_t)b * T + t] = bi;
+}
+int k_ctc_logsoftmax_argmax(const float* logits, int ld, float* log_probs, int32_t* argmax_ids, int B, int T, int C, hipStream_t s) {
+    OCRVI_CHECK(logits && B > 0 && T > 0 && C > 0 && C <= 1024 && ld >= C, OCRVI_EINVAL, "ctc: bad shape B=%d T=%d C=%d", B, T, C);
+    hipLaunchKernelGGL(ctc_logsoftmax_argmax_kernel, dim3(cdiv(B * T, 4)), dim3(256), 0, s, logits, ld, log_probs, argmax_ids, B, T, C);
+    OCRVI_HIP(hipGetLastError());
+    return OCRVI_OK;
+}
+
+__global__ void ctc_argmax_tbc_kernel(const float* __restrict__ lp, int32_t* __restrict__ argmax_ids, int B, int T, int C) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // t*B + b
+    if (row >= B * T) return;
+    const int t = row / B, b = row % B;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    bool any_nan = false;
+    for (int c = lane; c < C; c += 64) {
+        const float v = lp[(size_t)row * C + c];
+        any_nan |= (v != v);
+        if (v > best) { best = v; bi = c; }
+    }
+    if (bi == 0x7fffffff && !any_nan) bi = lane < C ? lane : 0x7fffffff;  // all -inf: first index
+    wave_argmax(best, bi);
+    if (lane == 0) argmax_ids[(size_t)b * T + t] = bi == 0x7fffffff ? 0 : bi;
+}
+int k_ctc_argmax_tbc(const float* log_probs, int32_t* argmax_ids, int B, int T, int C, hipStream_t s) {
+    OCRVI_CHECK(log_probs && argmax_ids && B > 0 && T > 0 && C > 0, OCRVI_EINVAL, "ctc argmax: bad shape");
+    hipLaunchKernelGGL(ctc_argmax_tbc_kernel, dim3(cdiv(B * T, 4)), dim3(256), 0, s, log_probs, argmax_ids, B, T, C);
+    OCRVI_HIP(hipGetLastError());
+    return OCRVI_OK;
+}
+
+// One wave per sequence; 64 time steps per pass, keep[t] = id != blank && id != previous id; compaction by ballot prefix count.
+__global__ void ctc_collapse_kernel(const int32_t* __restrict__ am, int32_t* __restrict__ ids, int32_t* __restrict__ lens, int B, int T, int blank) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int32_t* a = am + (size_t)b * T;
+    int32_t* o = ids ? ids + (size_t)b * T : nullptr;
+    int count = 0;
+    for (int t0 = 0; t0 < T; t0 += 64) {
+        const int t = t0 + lane;
+        const int cur = t < T ? a[t] : blank;
+        const int prev = (t > 0 && t < T) ? a[t - 1] : -1;
+        const bool keep = t < T && cur != blank && cur != prev;
+        const unsigned long long mask = __ballot(keep);
+        const int pos = count + __popcll(mask & ((1ull << lane) - 1ull));
+        if (keep && o) o[pos] = cur;
+        count += __popcll(mask);
+    }
+    if (o)
+        for (int t = count + lane; t < T; t += 64) o[t] = -1;
+    if (lens && lane == 0) lens[b] = count;
+}
+int k_ctc_collapse(const int32_t* argmax_ids, int32_t* ids, int32_t* lens, int B, int T, int blank, hipStream_t s) {
+    OCRVI_CHECK(argmax_ids && B > 0 && T > 0, OCRVI_EINVAL, "ctc collapse: bad shape");
+    hipLaunchKernelGGL(ctc_collapse_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, argmax_ids, ids, lens, B, T, blank);
+    OCRVI_HIP(hipGetLastError());
+    return OCRVI_OK;
+}
+
+}  // namespace ocrvi

@@ -1,0 +1,139 @@
+"""GPU parity of individual kernels, called through the C ABI test hooks (include/ocrvi.h), against torch fp32
+on the CPU / the oracle.  fp32-MFMA mode must match to 1e-4-ish; bf16 / fp16 modes are checked against an
+error budget relative to the output scale (stated per test)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DT = {"f32": 0, "bf16": 1, "f16": 2}
+# relative-to-output-rms budgets: f32 MFMA is an fmaf chain; bf16 has 8 mantissa bits, fp16 11
+TOL = {"f32": 2e-5, "bf16": 2e-2, "f16": 3e-3}
+
+
+def _lib():
+    from ocr_vi_invoice_amd import _lib as L
+    return L
+
+
+def _rel_err(a, b):
+    return float((a - b).abs().max() / (b.pow(2).mean().sqrt() + 1e-12))
+
+
+def run_conv(x, w, b, ks, sh, sw, groups, act, dt):
+    L = _lib()
+    lib = L.load()
+    N, Cin, H, W = x.shape
+    Co = w.shape[0]
+    pad = ks // 2
+    Ho, Wo = (H + 2 * pad - ks) // sh + 1, (W + 2 * pad - ks) // sw + 1
+    xd = x.cuda().contiguous()
+    out = torch.empty((N, Co, Ho, Wo), device="cuda")
+    wh = np.ascontiguousarray(w.numpy(), dtype=np.float32)
+    bh = np.ascontiguousarray(b.numpy(), dtype=np.float32) if b is not None else None
+    ms = C.c_float(0)
+    L.check(lib.ocrvi_test_conv(0, DT[dt], xd.data_ptr(), wh.ctypes.data, bh.ctypes.data if bh is not None else None,
+                                N, Cin, H, W, Co, ks, sh, sw, groups, act, out.data_ptr(), 0, C.byref(ms)))
+    return out.cpu()
+
+
+CONV_CASES = [
+    # N, Cin, H, W, Co, ks, sh, sw, groups, act
+    (2, 64, 12, 20, 64, 1, 1, 1, 1, 1),      # bottleneck conv1
+    (2, 64, 12, 20, 256, 1, 1, 1, 1, 0),
+    (1, 256, 10, 14, 128, 1, 2, 2, 1, 0),    # downsample 1x1 stride 2
+    (2, 64, 13, 17, 64, 3, 1, 1, 1, 1),      # ragged M
+    (1, 128, 16, 16, 128, 3, 2, 2, 1, 1),
+    (2, 128, 12, 20, 128, 3, 1, 1, 4, 2),    # LocalMixing grouped conv + GELU
+    (2, 128, 12, 20, 256, 3, 2, 1, 1, 0),    # PatchMerging stride (2,1)
+    (1, 128, 9, 11, 27, 3, 1, 1, 1, 0) ,     # narrow-N (offset-conv shaped, generic store path needs N%4: use 28)
+    (3, 96, 1, 1, 232, 1, 1, 1, 1, 0),       # Linear-shaped, K=96 (padded K), N=232
+]
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_kernel(case, dt):
+    N, Cin, H, W, Co, ks, sh, sw, groups, act = case
+    if Co == 27:
+        Co = 28
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Co, Cin // groups, ks, ks, generator=g) / np.sqrt(Cin // groups * ks * ks)
+    b = torch.randn(Co, generator=g) * 0.1
+    ref = F.conv2d(x, w, b, (sh, sw), ks // 2, 1, groups)
+    ref = F.relu(ref) if act == 1 else (F.gelu(ref) if act == 2 else ref)
+    out = run_conv(x, w, b, ks, sh, sw, groups, act, dt)
+    assert out.shape == ref.shape
+    assert _rel_err(out, ref) < TOL[dt], _rel_err(out, ref)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("stride", [1, 2])
+@pytest.mark.parametrize("C_", [128, 256])
+def test_deform_conv_kernel(C_, stride, dt):
+    from oracle import dbnet_cpu
+    L = _lib()
+    lib = L.load()
+    g = torch.Generator().manual_seed(11 + stride)
+    N, H, W, Co = 2, 14, 18, C_
+    x = torch.randn(N, C_, H, W, generator=g)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    off = torch.randn(N, 18, Ho, Wo, generator=g) * 3.0   # samples land outside the image too
+    mask = torch.rand(N, 9, Ho, Wo, generator=g)
+    w = torch.randn(Co, C_, 3, 3, generator=g) / np.sqrt(9 * C_)
+    b = torch.randn(Co, generator=g) * 0.1
+    ref = F.relu(dbnet_cpu.deform_conv2d_gather(x, off, mask, w, stride) + b.view(1, -1, 1, 1))
+    out = torch.empty((N, Co, Ho, Wo), device="cuda")
+    wh, bh = np.ascontiguousarray(w.numpy()), np.ascontiguousarray(b.numpy())
+    ms = C.c_float(0)
+    L.check(lib.ocrvi_test_deform_conv(0, DT[dt], x.cuda().data_ptr(), off.cuda().data_ptr(), mask.cuda().data_ptr(),
+                                       wh.ctypes.data, bh.ctypes.data, N, C_, H, W, Co, stride, 1, out.data_ptr(), 0, C.byref(ms)))
+    assert _rel_err(out.cpu(), ref) < TOL[dt], _rel_err(out.cpu(), ref)
+
+
+def test_deform_conv_zero_offset_identity():
+    """dcn.py:28-29 init: offsets 0 and mask 0.5 -> 0.5 * conv2d."""
+    L = _lib()
+    lib = L.load()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 128, 10, 12, generator=g)
+    w = torch.randn(128, 128, 3, 3, generator=g) / 34.0
+    ref = 0.5 * F.conv2d(x, w, None, 1, 1)
+    out = torch.empty((1, 128, 10, 12), device="cuda")
+    off = torch.zeros(1, 18, 10, 12, device="cuda")
+    mask = torch.full((1, 9, 10, 12), 0.5, device="cuda")
+    wh = np.ascontiguousarray(w.numpy())
+    ms = C.c_float(0)
+    L.check(lib.ocrvi_test_deform_conv(0, 0, x.cuda().data_ptr(), off.data_ptr(), mask.data_ptr(), wh.ctypes.data, None,
+                                       1, 128, 10, 12, 128, 1, 0, out.data_ptr(), 0, C.byref(ms)))
+    assert _rel_err(out.cpu(), ref) < 2e-5
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("B,N,heads", [(2, 480, 8), (3, 240, 12), (4, 80, 12), (2, 100, 2), (1, 512, 1), (2, 16, 3)])
+def test_attention_kernel(B, N, heads, dt):
+    L = _lib()
+    lib = L.load()
+    g = torch.Generator().manual_seed(N)
+    D = heads * 32
+    qkv = torch.randn(B, N, 3 * D, generator=g)
+    q, k, v = qkv.reshape(B, N, 3, heads, 32).permute(2, 0, 3, 1, 4)
+    ref = ((q @ k.transpose(-2, -1)) * 32 ** -0.5).softmax(-1) @ v
+    ref = ref.transpose(1, 2).reshape(B, N, D)
+    out = torch.empty((B, N, D), device="cuda")
+    ms = C.c_float(0)
+    L.check(lib.ocrvi_test_attention(0, DT[dt], qkv.cuda().data_ptr(), B, N, heads, out.data_ptr(), 0, C.byref(ms)))
+    assert _rel_err(out.cpu(), ref) < TOL[dt] * 1.5, _rel_err(out.cpu(), ref)
+
+
+def test_attention_rejects_long_sequences():
+    L = _lib()
+    qkv = torch.zeros(1, 600, 96, device="cuda")
+    out = torch.empty(1, 600, 32, device="cuda")
+    with pytest.raises(ValueError):
+        L.check(L.load().ocrvi_test_attention(0, 1, qkv.data_ptr(), 1, 600, 1, out.data_ptr(), 0, None))
