@@ -108,6 +108,19 @@ int ocrvi_ctc_greedy(int device, const float* log_probs, int T, int B, int C, in
                      int32_t* argmax_ids, int32_t* ids, int32_t* lens, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Pre-processing on the device (the callers either side of the two models on the e2e path).
+ * ------------------------------------------------------------------------------------------------ */
+/* Replaces the detection input normalisation of src/pipeline/pipeline2.py:312-314: images uint8 HWC
+ * [N,H,W,3] (device) -> float32 NCHW [N,3,H,W] = ((v/255 as float32) - mean) / std evaluated in float64. */
+int ocrvi_normalize_u8(int device, const uint8_t* images, int N, int H, int W, float* out, void* stream);
+/* Replaces crop_image (src/det/test.py:123-130, box already reduced to its clamped bounding rect) followed by
+ * preprocess_for_recognition (src/pipeline/pipeline2.py:92-128) for a batch of crops.  images uint8 HWC
+ * [n_img,H,W,3]; boxes int32 [B,5] = (image index, x, y, w, h) in pixels, inside the image; out float32
+ * [B,3,out_h,out_w].  w<=0 or h<=0 yields the all-zero tensor of pipeline2.py:154-156. */
+int ocrvi_crop_resize_normalize(int device, const uint8_t* images, int n_img, int H, int W, const int32_t* boxes, int B,
+                                int out_h, int out_w, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Kernel-level test/bench hooks (same kernels the models launch; used by tests/ and bench.py for
  * per-kernel parity and roofline timing).
  * ------------------------------------------------------------------------------------------------ */
@@ -127,6 +140,13 @@ int ocrvi_test_conv(int device, int dtype, const float* x, const float* weight_h
  * qkv.reshape(B,N,3,heads,32), svtrv2.py:80) -> out [B, N, heads*32] float32 (svtrv2.py:82-85). */
 int ocrvi_test_attention(int device, int dtype, const float* qkv, int B, int N, int heads, float* out, int iters,
                          float* avg_ms);
+
+/* Per-launch HIP-event profiler (process-global, off by default).  While enabled every MFMA / bandwidth kernel launch
+ * of the graphs above is bracketed by two events recorded on its launch stream.  ocrvi_prof_report synchronises those
+ * events and writes a JSON object {tag: {launches, ms, flops, bytes}} (algorithmic FLOPs / bytes per tag) into buf. */
+int ocrvi_prof_enable(int on);
+int ocrvi_prof_reset(void);
+int ocrvi_prof_report(char* buf, size_t cap);
 
 #ifdef __cplusplus
 }

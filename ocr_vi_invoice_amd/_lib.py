@@ -18,7 +18,8 @@ EXPORTS = [
     "ocrvi_last_error", "ocrvi_abi_version",
     "ocrvi_det_create", "ocrvi_det_destroy", "ocrvi_det_workspace_bytes", "ocrvi_det_forward", "ocrvi_det_debug_features",
     "ocrvi_rec_create", "ocrvi_rec_destroy", "ocrvi_rec_workspace_bytes", "ocrvi_rec_forward", "ocrvi_rec_debug_features",
-    "ocrvi_ctc_greedy", "ocrvi_test_deform_conv", "ocrvi_test_conv", "ocrvi_test_attention",
+    "ocrvi_ctc_greedy", "ocrvi_normalize_u8", "ocrvi_crop_resize_normalize", "ocrvi_test_deform_conv", "ocrvi_test_conv", "ocrvi_test_attention",
+    "ocrvi_prof_enable", "ocrvi_prof_reset", "ocrvi_prof_report",
 ]
 
 
@@ -42,6 +43,9 @@ def load() -> C.CDLL:
         raise RuntimeError(
             f"libocrvi.so not found at {LIB_PATH}: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C ocr_vi_invoice_amd/csrc`).  There is no CPU fallback for the product path.")
+    # torch must own the HIP runtime: importing it first makes libocrvi's libamdhip64 dependency resolve to the copy torch
+    # already loaded, so streams, device pointers and the device context are shared (a second runtime sees no device).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     vp, i32, f32p, i32p, sz = C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t
     lib.ocrvi_last_error.restype = C.c_char_p
@@ -60,11 +64,16 @@ def load() -> C.CDLL:
     lib.ocrvi_rec_forward.argtypes = [vp, f32p, i32, i32, i32, f32p, i32p, i32p, i32p, vp, sz, vp]
     lib.ocrvi_rec_debug_features.argtypes = [vp, i32, i32, i32, f32p, f32p, vp, sz, vp]
     lib.ocrvi_ctc_greedy.argtypes = [i32, f32p, i32, i32, i32, i32, i32p, i32p, i32p, vp]
+    lib.ocrvi_normalize_u8.argtypes = [i32, vp, i32, i32, i32, f32p, vp]
+    lib.ocrvi_crop_resize_normalize.argtypes = [i32, vp, i32, i32, i32, i32p, i32, i32, i32, f32p, vp]
     lib.ocrvi_test_deform_conv.argtypes = [i32, i32, f32p, f32p, f32p, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32p, i32,
                                            C.POINTER(C.c_float)]
     lib.ocrvi_test_conv.argtypes = [i32, i32, f32p, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32p, i32,
                                     C.POINTER(C.c_float)]
     lib.ocrvi_test_attention.argtypes = [i32, i32, f32p, i32, i32, i32, f32p, i32, C.POINTER(C.c_float)]
+    lib.ocrvi_prof_enable.argtypes = [i32]
+    lib.ocrvi_prof_reset.argtypes = []
+    lib.ocrvi_prof_report.argtypes = [C.c_char_p, sz]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("ocrvi_last_error", "ocrvi_det_destroy", "ocrvi_rec_destroy"):
@@ -103,3 +112,11 @@ def dtype_code(dtype) -> int:
 def ptr(t) -> Optional[int]:
     """Device pointer of a torch tensor (or None)."""
     return None if t is None else t.data_ptr()
+
+
+def prof_report() -> dict:
+    """Aggregated per-kernel-tag timings recorded since the last reset (see ocrvi_prof_report)."""
+    import json
+    buf = C.create_string_buffer(1 << 16)
+    check(load().ocrvi_prof_report(buf, len(buf)))
+    return json.loads(buf.value.decode())

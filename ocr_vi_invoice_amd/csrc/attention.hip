@@ -202,6 +202,10 @@ static int attn_dt(const void* qkv, void* out, int B, int N, int heads, hipStrea
 int k_attention(int dtype, const void* qkv, void* out, int B, int N, int heads, hipStream_t s) {
     OCRVI_CHECK(qkv && out && B > 0 && B < 65536 && heads > 0 && N > 0, OCRVI_EINVAL, "attention: bad shape B=%d N=%d heads=%d", B, N, heads);
     OCRVI_CHECK(N <= 512, OCRVI_EINVAL, "attention: sequence length %d > 512 unsupported (crop wider than ~340 px at height 48)", N);
+    char tag[64];
+    snprintf(tag, sizeof(tag), "attention_hd32_%s", dtype_name(dtype));
+    const double esz = (double)dtype_size(dtype);
+    ProfScope ps(tag, 4.0 * B * heads * (double)N * N * 32, (double)B * N * heads * 32 * 4 * esz, s);
     switch (dtype) {
         case OCRVI_F32: return attn_dt<float>(qkv, out, B, N, heads, s);
         case OCRVI_BF16: return attn_dt<bf16_t>(qkv, out, B, N, heads, s);

@@ -176,6 +176,18 @@ struct Blob {
     int get(const std::string& name, int d0, int d1, int d2, int d3, const BlobTensor** out) const;
 };
 
+// ---------------------------------------------------------------- per-launch HIP-event profiler (off by default)
+// When enabled (ocrvi_prof_enable), every instrumented launch is bracketed by two events recorded on the launch
+// stream; ocrvi_prof_report aggregates elapsed time, algorithmic FLOPs and algorithmic bytes per kernel tag.
+bool prof_enabled();
+struct ProfScope {
+    int slot = -1;
+    hipStream_t stream;
+    ProfScope(const char* tag, double flops, double bytes, hipStream_t s);
+    ~ProfScope();
+};
+static inline const char* dtype_name(int dt) { return dt == OCRVI_F32 ? "f32" : (dt == OCRVI_BF16 ? "bf16" : "f16"); }
+
 // Host fp32 -> T conversion into a byte buffer.
 void convert_to_dtype(const float* src, size_t n, int dtype, void* dst);
 

@@ -2,6 +2,9 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
+
 #include "conv_gemm.h"
 
 namespace ocrvi {
@@ -147,7 +150,55 @@ PackedConv pack_deconv2(const float* w, const float* bias, int cin, int cout, in
     return pc;
 }
 
+// ------------------------------------------------------------------ profiler
+namespace {
+struct ProfEntry { std::string tag; double flops, bytes; hipEvent_t e0, e1; };
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<ProfEntry> g_prof;
+}  // namespace
+bool prof_enabled() { return g_prof_on; }
+ProfScope::ProfScope(const char* tag, double flops, double bytes, hipStream_t s) : stream(s) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfEntry e;
+    e.tag = tag; e.flops = flops; e.bytes = bytes;
+    if (hipEventCreate(&e.e0) != hipSuccess || hipEventCreate(&e.e1) != hipSuccess) return;
+    (void)hipEventRecord(e.e0, s);
+    g_prof.push_back(e);
+    slot = (int)g_prof.size() - 1;
+}
+ProfScope::~ProfScope() {
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    (void)hipEventRecord(g_prof[slot].e1, stream);
+}
+
+static const char* amode_name(int amode, const ConvParams& p) {
+    switch (amode) {
+        case AM_CONV1: return p.store_mode == ST_SHUFFLE2 ? "deconv2x2" : "conv1x1";
+        case AM_CONV3: return p.store_mode == ST_DCN_OFFS ? "dcn_offset_conv3x3" : (p.groups > 1 ? "gconv3x3" : "conv3x3");
+        case AM_ROWS: return "stem_conv";
+        case AM_DCN: return "dcn3x3";
+    }
+    return "conv";
+}
+
 int launch_conv_dt(int dtype, const ConvParams& p, int amode, hipStream_t stream) {
+    char tag[96];
+    double flops = 0, bytes = 0;
+    if (g_prof_on) {
+        const int ks = amode == AM_CONV1 ? 1 : (amode == AM_ROWS ? p.KH : 3);
+        const double kvalid = amode == AM_ROWS ? (double)p.KH * p.KH * 3 : (double)ks * ks * p.Cin_g;
+        const double esz = (double)dtype_size(dtype);
+        flops = 2.0 * p.M * p.N_g * p.groups * kvalid;
+        // algorithmic bytes: input read once, weights once, output written once (+ residual / offsets read once)
+        bytes = (double)p.n_img * p.H * p.W * (amode == AM_ROWS ? 4 : p.Cin_g * p.groups) * esz + (double)p.N_g * p.groups * kvalid * esz +
+                (double)p.M * p.N_g * p.groups * (p.out_f32 ? 4.0 : esz) + (p.res ? (double)p.M * p.N_g * p.groups * (p.res_f32 ? 4.0 : esz) : 0.0) +
+                (p.offs ? (double)p.M * 27 * 4 : 0.0);
+        snprintf(tag, sizeof(tag), "%s_128x%d_%s", amode_name(amode, p), conv_bn_for(p.N_g), dtype_name(dtype));
+    }
+    ProfScope ps(tag, flops, bytes, stream);
     switch (dtype) {
         case OCRVI_F32: return launch_conv<float>(p, amode, stream);
         case OCRVI_BF16: return launch_conv<bf16_t>(p, amode, stream);
@@ -158,6 +209,45 @@ int launch_conv_dt(int dtype, const ConvParams& p, int amode, hipStream_t stream
 }
 
 }  // namespace ocrvi
+
+extern "C" int ocrvi_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(ocrvi::g_prof_mu);
+    ocrvi::g_prof_on = on != 0;
+    return OCRVI_OK;
+}
+extern "C" int ocrvi_prof_reset(void) {
+    std::lock_guard<std::mutex> lk(ocrvi::g_prof_mu);
+    for (auto& e : ocrvi::g_prof) { (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); }
+    ocrvi::g_prof.clear();
+    return OCRVI_OK;
+}
+extern "C" int ocrvi_prof_report(char* buf, size_t cap) {
+    using namespace ocrvi;
+    OCRVI_CHECK(buf && cap > 2, OCRVI_EINVAL, "prof_report: null buffer");
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    struct Agg { double ms = 0, flops = 0, bytes = 0; long n = 0; };
+    std::map<std::string, Agg> agg;
+    for (auto& e : g_prof) {
+        OCRVI_HIP(hipEventSynchronize(e.e1));
+        float ms = 0.f;
+        OCRVI_HIP(hipEventElapsedTime(&ms, e.e0, e.e1));
+        Agg& a = agg[e.tag];
+        a.ms += ms; a.flops += e.flops; a.bytes += e.bytes; a.n += 1;
+    }
+    std::string js = "{";
+    bool first = true;
+    for (auto& kv : agg) {
+        char line[256];
+        snprintf(line, sizeof(line), "%s\"%s\": {\"launches\": %ld, \"ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e}", first ? "" : ", ",
+                 kv.first.c_str(), kv.second.n, kv.second.ms, kv.second.flops, kv.second.bytes);
+        js += line;
+        first = false;
+    }
+    js += "}";
+    OCRVI_CHECK(js.size() + 1 <= cap, OCRVI_ENOMEM, "prof_report: buffer too small (%zu needed)", js.size() + 1);
+    memcpy(buf, js.c_str(), js.size() + 1);
+    return OCRVI_OK;
+}
 
 extern "C" const char* ocrvi_last_error(void) { return ocrvi::last_error_cstr(); }
 extern "C" int ocrvi_abi_version(void) { return 1; }

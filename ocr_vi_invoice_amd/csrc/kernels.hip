@@ -65,6 +65,7 @@ __global__ void nchw3_to_nhwc4_pad_kernel(const float* __restrict__ x, T* __rest
 }
 int k_nchw3_to_nhwc4_pad(int dtype, const float* x, void* y, int N, int H, int W, int pad_t, int pad_l, int Hp, int Wp, hipStream_t s) {
     OCRVI_CHECK(x && y && N > 0 && Hp >= H + pad_t && Wp >= W + pad_l, OCRVI_EINVAL, "nhwc4 pad: bad shape");
+    ProfScope ps_("nchw_to_nhwc4", 0.0, (double)N*(H*W*12.0+(double)Hp*Wp*4*dtype_size(dtype)), s);
     const size_t total = (size_t)N * Hp * Wp;
     const int grid = (int)std::min<size_t>((total + 255) / 256, 8192);
     DISPATCH_DT(dtype, hipLaunchKernelGGL(nchw3_to_nhwc4_pad_kernel<T>, dim3(grid), dim3(256), 0, s, x, (T*)y, N, H, W, pad_t, pad_l, Hp, Wp));
@@ -106,6 +107,7 @@ __global__ void maxpool3x3s2_kernel(const T* __restrict__ x, T* __restrict__ y, 
 }
 int k_maxpool3x3s2(int dtype, const void* x, void* y, int N, int H, int W, int C, hipStream_t s) {
     OCRVI_CHECK(x && y && C % 8 == 0 && H >= 2 && W >= 2, OCRVI_EINVAL, "maxpool: bad shape C=%d", C);
+    ProfScope ps_("maxpool3x3s2", 0.0, (double)N*H*W*C*dtype_size(dtype)*1.25, s);
     const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
     const size_t total = (size_t)N * OH * OW * (C / (dtype == OCRVI_F32 ? 4 : 8));
     const int grid = (int)std::min<size_t>((total + 255) / 256, 16384);
@@ -159,6 +161,7 @@ __global__ void layernorm_kernel(const TI* __restrict__ x, TO* __restrict__ out,
 int k_layernorm(int dtype, const void* x, int x_f32, void* out, int out_f32, const float* gamma, const float* beta, int rows, int D,
                 hipStream_t s) {
     OCRVI_CHECK(x && out && gamma && beta && rows > 0 && D % 4 == 0 && D <= 1024, OCRVI_EINVAL, "layernorm: bad shape rows=%d D=%d", rows, D);
+    ProfScope ps_("layernorm", 0.0, (double)rows*D*((x_f32?4:dtype_size(dtype))+(out_f32?4:dtype_size(dtype))), s);
     const dim3 grid(cdiv(rows, 4)), block(256);
     DISPATCH_DT(dtype, {
         if (x_f32 && out_f32) hipLaunchKernelGGL((layernorm_kernel<float, float>), grid, block, 0, s, (const float*)x, (float*)out, gamma, beta, rows, D);
@@ -323,6 +326,7 @@ __global__ __launch_bounds__(256) void asf_kernel(const T* __restrict__ p2, cons
 int k_asf(int dtype, const void* p2, const void* p3, const void* p4, const void* p5, const float* w, const float* b, void* out, int N,
           int H, int W, hipStream_t s) {
     OCRVI_CHECK(p2 && p3 && p4 && p5 && w && b && out && H % 8 == 0 && W % 8 == 0, OCRVI_EINVAL, "asf: bad shape %dx%d", H, W);
+    ProfScope ps_("asf_fused", 0.0, (double)N*H*W*256*dtype_size(dtype)*(2.0+1.0/4+1.0/16+1.0/64), s);
     const size_t total = (size_t)N * H * W;
     const int grid = (int)std::min<size_t>((total + 3) / 4, 256 * 8);
     DISPATCH_DT(dtype, hipLaunchKernelGGL(asf_kernel<T>, dim3(grid), dim3(256), 0, s, (const T*)p2, (const T*)p3, (const T*)p4, (const T*)p5, w, b, (T*)out, N, H, W));
@@ -380,6 +384,7 @@ __global__ __launch_bounds__(256) void db_tail_kernel(const T* __restrict__ y, c
 int k_db_tail(int dtype, const void* y, const float* w2, const float* b2, float k, float* binary, float* thresh, float* thresh_binary,
               float* bin_logits, float* thresh_logits, int N, int H2, int W2, hipStream_t s) {
     OCRVI_CHECK(y && w2 && b2 && binary && N > 0, OCRVI_EINVAL, "db tail: null operand");
+    ProfScope ps_("db_head_tail", 0.0, (double)N*H2*W2*(128.0*dtype_size(dtype)+16.0*((thresh?1:0)+(thresh_binary?1:0)+(bin_logits?1:0)+(thresh_logits?1:0)+1)), s);
     const size_t total = (size_t)N * H2 * W2;
     const int grid = (int)std::min<size_t>((total + 255) / 256, 256 * 16);
     DISPATCH_DT(dtype, hipLaunchKernelGGL(db_tail_kernel<T>, dim3(grid), dim3(256), 0, s, (const T*)y, w2, b2, k, binary, thresh, thresh_binary, bin_logits, thresh_logits, N, H2, W2));
@@ -436,6 +441,7 @@ __global__ void ctc_logsoftmax_argmax_kernel(const float* __restrict__ logits, i
 }
 int k_ctc_logsoftmax_argmax(const float* logits, int ld, float* log_probs, int32_t* argmax_ids, int B, int T, int C, hipStream_t s) {
     OCRVI_CHECK(logits && B > 0 && T > 0 && C > 0 && C <= 1024 && ld >= C, OCRVI_EINVAL, "ctc: bad shape B=%d T=%d C=%d", B, T, C);
+    ProfScope ps_("ctc_logsoftmax_argmax", 0.0, (double)B*T*C*(log_probs?8.0:4.0), s);
     hipLaunchKernelGGL(ctc_logsoftmax_argmax_kernel, dim3(cdiv(B * T, 4)), dim3(256), 0, s, logits, ld, log_probs, argmax_ids, B, T, C);
     OCRVI_HIP(hipGetLastError());
     return OCRVI_OK;

@@ -37,8 +37,9 @@ def make_invoice(seed: int, height: int = 960, width: int = 1280, lines: int = 3
     pitch = (height - 40) // lines
     for i in range(lines):
         h = int(rng.integers(max(pitch // 2, 8), max(pitch - 4, 9)))
-        w = int(rng.integers(width // 8, width - 80))
-        x0 = int(rng.integers(20, max(width - w - 20, 21)))
+        lo = max(width // 8, 8)
+        w = int(rng.integers(lo, max(width - 16, lo + 1)))
+        x0 = int(rng.integers(4, max(width - w - 4, 5)))
         y0 = 20 + i * pitch
         _draw_line(img, rng, x0, y0, w, h)
         boxes.append((x0, y0, w, h))
