@@ -117,6 +117,6 @@ def ptr(t) -> Optional[int]:
 def prof_report() -> dict:
     """Aggregated per-kernel-tag timings recorded since the last reset (see ocrvi_prof_report)."""
     import json
-    buf = C.create_string_buffer(1 << 16)
+    buf = C.create_string_buffer(1 << 20)
     check(load().ocrvi_prof_report(buf, len(buf)))
     return json.loads(buf.value.decode())

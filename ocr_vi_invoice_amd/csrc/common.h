@@ -100,6 +100,12 @@ template <> struct Chunk<f16_t> {
 // operands, which a dot product does not care about.
 template <typename T> struct Mma;
 template <> struct Mma<float> {
+    __device__ static inline void half(const uint4& a, const uint4& b, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+    }
     __device__ static inline void run(const uint4 (&a)[2], const uint4 (&b)[2], f32x4& c) {
         const uint32_t aw[8] = {a[0].x, a[0].y, a[0].z, a[0].w, a[1].x, a[1].y, a[1].z, a[1].w};
         const uint32_t bw[8] = {b[0].x, b[0].y, b[0].z, b[0].w, b[1].x, b[1].y, b[1].z, b[1].w};
@@ -109,6 +115,9 @@ template <> struct Mma<float> {
     }
 };
 template <> struct Mma<bf16_t> {
+    __device__ static inline void half(const uint4& a, const uint4& b, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
     __device__ static inline void run(const uint4 (&a)[2], const uint4 (&b)[2], f32x4& c) {
 #pragma unroll
         for (int s = 0; s < 2; ++s)
@@ -116,6 +125,9 @@ template <> struct Mma<bf16_t> {
     }
 };
 template <> struct Mma<f16_t> {
+    __device__ static inline void half(const uint4& a, const uint4& b, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
     __device__ static inline void run(const uint4 (&a)[2], const uint4 (&b)[2], f32x4& c) {
 #pragma unroll
         for (int s = 0; s < 2; ++s)
@@ -127,7 +139,19 @@ template <> struct Mma<f16_t> {
 // conflict-free under the gfx950 lane-group / 64-bank rule (checked by simulation).
 __device__ __forceinline__ int swz128(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 2); }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e. fp32 round-off level): 1 rcp + 1 exp + 6 fma instead of
+// libm erff's ~50-instruction polynomial ladder, which made the GELU epilogue several times the MFMA main loop.
+__device__ __forceinline__ float erf_as(float x) {
+    const float ax = fabsf(x);
+    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float r = 1.0f - p * t * __expf(-ax * ax);
+    return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 // XCD-aware block remap (cdna_hip_programming.md T1, bijective form): consecutive logical tiles land on one XCD.

@@ -41,55 +41,92 @@ struct ConvParams {
     int res_post = 0;  // 0: act(acc + bias + res) (ResNet);  1: act(acc + bias) + res (x + mixer(..), svtrv2.py:98-101)
     int Hp = 0, Wp = 0;
     int shuffle_co = 0;  // ST_SHUFFLE2: channels per output pixel (n = (a*2+b)*shuffle_co + co)
+    unsigned long long mg_ow = 0, mg_oh = 0;  // floor(2^40/d)+1: n/d == (n*mg)>>40 for n < 2^23 (filled by launch_conv)
+    int identity_pix = 0;  // 1x1, stride 1, pad 0: input pixel index == m (no decomposition needed)
+    int epi_lds = 0;       // stage the output tile through LDS and store whole rows (ST_NHWC only; set by launch_conv)
 };
 
-template <typename T, int AMODE, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
+__device__ __forceinline__ int fastdiv(int n, unsigned long long mg) { return (int)(((unsigned long long)(unsigned)n * mg) >> 40); }
+
+// Resident workgroups per CU the launcher sizes the persistent grid for (bounded by VGPRs: 168 / 112 / 88 per lane).
+template <int AMODE, int BM, int BN> struct ConvOcc { static constexpr int value = AMODE == AM_DCN ? 2 : (BN >= 128 ? 3 : (BN >= 64 ? 4 : 5)); };
+
+// Persistent implicit-GEMM kernel.  A workgroup (4 waves) walks output tiles  first, first+G, first+2G, ...  One LDS stage
+// (A tile + W tile, 128 B of K per row); global loads for the NEXT K-step -- or the next TILE's first K-step -- are issued
+// into registers before the MFMAs of the current one and written to LDS after them, so the load latency, the MFMA phase, the
+// epilogue and the store drain of consecutive tiles overlap (most layers here have only 1..8 K-steps per tile, so a
+// one-tile-per-workgroup kernel runs load -> MFMA -> store strictly in series).
+// PERSIST = false (shipped): one tile per workgroup.  Measured on MI355X (profiles/r01_conv_variants.md): holding the next
+// tile's loads across the epilogue costs ~40 VGPRs, i.e. one resident workgroup per CU, and loses 10-35 % on every shape;
+// occupancy (3-5 workgroups per CU) hides more latency than cross-tile prefetch does.
+template <typename T, int AMODE, int BM, int BN, int WM, int WN, bool PERSIST>
+__global__ __launch_bounds__(256, (ConvOcc<AMODE, BM, BN>::value)) void conv_gemm_kernel(const ConvParams p) {
     constexpr int EPC = TypeInfo<T>::EPC;  // elements per 16-byte chunk
     constexpr int BKE = 8 * EPC;           // elements per K-step (128 bytes)
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int MI = TM / 16, NI = TN / 16;
     constexpr int APASS = BM / 32, BPASS = BN / 32;
+    constexpr int LDS_BYTES = (BM + BN) * 128;
     static_assert(WM * WN == 4, "4 waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    auto As = [&](int buf) -> char* { return smem + buf * (BM + BN) * 128; };
-    auto Bs = [&](int buf) -> char* { return smem + buf * (BM + BN) * 128 + BM * 128; };
+    char* const As = smem;
+    char* const Bs = smem + BM * 128;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int ntiles = p.Np / BN;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int nt = tile % ntiles, mt = tile / ntiles;
+    const int total = ((p.M + BM - 1) / BM) * ntiles;
+    const int G = gridDim.x;
     const int grp = blockIdx.y;
-    const int m0 = mt * BM, n0 = nt * BN;
     const T* __restrict__ X = (const T*)p.x;
     const T* __restrict__ Wt = (const T*)p.w + (size_t)grp * p.Np * p.Kp;
+    const int cbase = p.cin_off + grp * p.Cin_g;
+    const int lrow = tid >> 3, j = tid & 7;  // staging geometry: rows lrow+32*i, 16-byte chunk j
+    const int lr = lane & 15, g = lane >> 4;
+    const int sw = swz128(lr);
+    const int fo0 = ((2 * g) ^ sw) << 4, fo1 = ((2 * g + 1) ^ sw) << 4;
+    const int nk = p.Kp / BKE;
 
-    // ---- per-thread staging geometry: rows (tid>>3)+32*i, 16-byte chunk j = tid&7
-    const int lrow = tid >> 3, j = tid & 7;
+    int m0 = 0, n0 = 0;
     int a_pix[APASS], a_ih0[APASS], a_iw0[APASS];
     size_t a_base[APASS];
     bool a_ok[APASS];
+
+    auto setup = [&](int tile) {  // n-tile fastest: neighbouring workgroups share the A rows through L2
+        const int mt = tile / ntiles;
+        n0 = (tile - mt * ntiles) * BN;
+        m0 = mt * BM;
 #pragma unroll
-    for (int i = 0; i < APASS; ++i) {
-        const int m = m0 + lrow + 32 * i;
-        a_ok[i] = m < p.M;
-        const int mm = a_ok[i] ? m : 0;
-        const int ow = mm % p.OW, t = mm / p.OW, oh = t % p.OH, img = t / p.OH;
-        a_ih0[i] = oh * p.SH - p.PH;
-        a_iw0[i] = ow * p.SW - p.PW;
-        a_pix[i] = img * p.H * p.W;
-        if constexpr (AMODE == AM_ROWS) a_base[i] = ((size_t)(img * p.Hp + oh * p.SH) * p.Wp + ow * p.SW) * 4;
-        if constexpr (AMODE == AM_DCN) a_base[i] = (size_t)mm * 32;
-    }
-    const int cbase = p.cin_off + grp * p.Cin_g;
+        for (int i = 0; i < APASS; ++i) {
+            const int m = m0 + lrow + 32 * i;
+            a_ok[i] = m < p.M;
+            const int mm = a_ok[i] ? m : 0;
+            int ow = 0, oh = 0, img = 0;
+            if (AMODE == AM_CONV1 && p.identity_pix) {
+                a_pix[i] = mm;  // input pixel == output pixel
+            } else {
+                const int t = fastdiv(mm, p.mg_ow);
+                ow = mm - t * p.OW;
+                img = fastdiv(t, p.mg_oh);
+                oh = t - img * p.OH;
+                a_pix[i] = img * p.H * p.W;
+            }
+            a_ih0[i] = oh * p.SH - p.PH;
+            a_iw0[i] = ow * p.SW - p.PW;
+            if constexpr (AMODE == AM_ROWS) a_base[i] = ((size_t)(img * p.Hp + oh * p.SH) * p.Wp + ow * p.SW) * 4;
+            if constexpr (AMODE == AM_DCN) a_base[i] = (size_t)mm * 32;
+        }
+    };
 
     struct Stage {
         uint4 a[APASS];
         uint4 b[BPASS];
         uint4 c[AMODE == AM_DCN ? APASS : 1][4];
-        float cw[AMODE == AM_DCN ? APASS : 1][4];
     } st;
+    // AM_DCN: sampling geometry of the current tap, reused by every K-step of that tap (Cin_g / BKE of them)
+    float dcw[AMODE == AM_DCN ? APASS : 1][4];   // bilinear weight x mask per corner (0 when the corner is outside)
+    int dco[AMODE == AM_DCN ? APASS : 1][4];     // clamped corner pixel offset inside the image
+    int dc_tap = -1;
 
     auto issue = [&](int ks) {
         // weights: rows lrow+32*i of the N tile, always in range (padded)
@@ -107,7 +144,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
                 const int ih = a_ih0[i] + r, iw = a_iw0[i] + s;
                 const bool ok = a_ok[i] && tap_ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
                 uint4 v = make_uint4(0, 0, 0, 0);
-                if (ok) v = *(const uint4*)(X + (size_t)(a_pix[i] + ih * p.W + iw) * p.Cin + cbase + c);
+                if (ok) v = *(const uint4*)(X + (size_t)(a_pix[i] + ih * p.W + iw) * p.Cin + cbase + c);  // identity_pix: ih = iw = 0
                 st.a[i] = v;
             }
         } else if constexpr (AMODE == AM_ROWS) {
@@ -121,38 +158,45 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
             }
         } else {  // AM_DCN: tap is uniform over the K-step (Cin_g % BKE == 0)
             const int tap = (ks * BKE) / p.Cin_g, c = koff - tap * p.Cin_g;
-            const int r = tap / 3, s = tap - r * 3;
-            const bool tap_ok = tap < 9;
-            const int tp = tap_ok ? tap : 0;
+            if (tap != dc_tap) {  // workgroup-uniform: first K-step of a new tap
+                dc_tap = tap;
+                const int r = tap / 3, s = tap - r * 3;
+                const bool tap_ok = tap < 9;
+                const int tp = tap_ok ? tap : 0;
+#pragma unroll
+                for (int i = 0; i < APASS; ++i) {
+                    const float* o = p.offs + a_base[i];
+                    const float dy = o[2 * tp], dx = o[2 * tp + 1], mk = o[18 + tp];
+                    const float py = (float)(a_ih0[i] + r) + dy, px = (float)(a_iw0[i] + s) + dx;
+                    const bool inside = a_ok[i] && tap_ok && py > -1.f && py < (float)p.H && px > -1.f && px < (float)p.W;
+                    // clamp before float->int so wild / NaN offsets cannot overflow (their weight is already 0)
+                    const float cy = fminf(fmaxf(py, -2.f), (float)p.H + 1.f), cx = fminf(fmaxf(px, -2.f), (float)p.W + 1.f);
+                    const float fy = floorf(cy), fx = floorf(cx);
+                    const float ly = cy - fy, lx = cx - fx, hy = 1.f - ly, hx = 1.f - lx;
+                    const int y0 = (int)fy, x0 = (int)fx, y1 = y0 + 1, x1 = x0 + 1;
+                    const bool oy0 = y0 >= 0, oy1 = y1 <= p.H - 1, ox0 = x0 >= 0, ox1 = x1 <= p.W - 1;
+                    const float m = inside ? mk : 0.f;
+                    dcw[i][0] = (oy0 && ox0) ? hy * hx * m : 0.f;
+                    dcw[i][1] = (oy0 && ox1) ? hy * lx * m : 0.f;
+                    dcw[i][2] = (oy1 && ox0) ? ly * hx * m : 0.f;
+                    dcw[i][3] = (oy1 && ox1) ? ly * lx * m : 0.f;
+                    const int yc0 = min(max(y0, 0), p.H - 1), yc1 = min(max(y1, 0), p.H - 1);
+                    const int xc0 = min(max(x0, 0), p.W - 1), xc1 = min(max(x1, 0), p.W - 1);
+                    dco[i][0] = a_pix[i] + yc0 * p.W + xc0;
+                    dco[i][1] = a_pix[i] + yc0 * p.W + xc1;
+                    dco[i][2] = a_pix[i] + yc1 * p.W + xc0;
+                    dco[i][3] = a_pix[i] + yc1 * p.W + xc1;
+                }
+            }
 #pragma unroll
             for (int i = 0; i < APASS; ++i) {
-                const float* o = p.offs + a_base[i];
-                const float dy = o[2 * tp], dx = o[2 * tp + 1], mk = o[18 + tp];
-                const float py = (float)(a_ih0[i] + r) + dy, px = (float)(a_iw0[i] + s) + dx;
-                const bool inside = a_ok[i] && tap_ok && py > -1.f && py < (float)p.H && px > -1.f && px < (float)p.W;
-                // clamp before float->int so wild / NaN offsets cannot overflow (their weight is already 0)
-                const float cy = fminf(fmaxf(py, -2.f), (float)p.H + 1.f), cx = fminf(fmaxf(px, -2.f), (float)p.W + 1.f);
-                const float fy = floorf(cy), fx = floorf(cx);
-                const float ly = cy - fy, lx = cx - fx, hy = 1.f - ly, hx = 1.f - lx;
-                const int y0 = (int)fy, x0 = (int)fx, y1 = y0 + 1, x1 = x0 + 1;
-                const bool oy0 = y0 >= 0, oy1 = y1 <= p.H - 1, ox0 = x0 >= 0, ox1 = x1 <= p.W - 1;
-                const float m = inside ? mk : 0.f;
-                st.cw[i][0] = (oy0 && ox0) ? hy * hx * m : 0.f;
-                st.cw[i][1] = (oy0 && ox1) ? hy * lx * m : 0.f;
-                st.cw[i][2] = (oy1 && ox0) ? ly * hx * m : 0.f;
-                st.cw[i][3] = (oy1 && ox1) ? ly * lx * m : 0.f;
-                const int yc0 = min(max(y0, 0), p.H - 1), yc1 = min(max(y1, 0), p.H - 1);
-                const int xc0 = min(max(x0, 0), p.W - 1), xc1 = min(max(x1, 0), p.W - 1);
-                const T* base = X + (size_t)a_pix[i] * p.Cin + cbase + c;
-                st.c[i][0] = *(const uint4*)(base + (size_t)(yc0 * p.W + xc0) * p.Cin);
-                st.c[i][1] = *(const uint4*)(base + (size_t)(yc0 * p.W + xc1) * p.Cin);
-                st.c[i][2] = *(const uint4*)(base + (size_t)(yc1 * p.W + xc0) * p.Cin);
-                st.c[i][3] = *(const uint4*)(base + (size_t)(yc1 * p.W + xc1) * p.Cin);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) st.c[i][q] = *(const uint4*)(X + (size_t)dco[i][q] * p.Cin + cbase + c);
             }
         }
     };
 
-    auto commit = [&](int buf) {
+    auto commit = [&]() {
         if constexpr (AMODE == AM_DCN) {
 #pragma unroll
             for (int i = 0; i < APASS; ++i) {
@@ -163,7 +207,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
                 for (int q = 0; q < 4; ++q) {
                     Chunk<T>::unpack(st.c[i][q], f);
 #pragma unroll
-                    for (int e = 0; e < EPC; ++e) acc[e] = fmaf(st.cw[i][q], f[e], acc[e]);
+                    for (int e = 0; e < EPC; ++e) acc[e] = fmaf(dcw[i][q], f[e], acc[e]);
                 }
                 st.a[i] = Chunk<T>::pack(acc);
             }
@@ -171,136 +215,206 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
 #pragma unroll
         for (int i = 0; i < APASS; ++i) {
             const int row = lrow + 32 * i;
-            *(uint4*)(As(buf) + row * 128 + ((j ^ swz128(row)) << 4)) = st.a[i];
+            *(uint4*)(As + row * 128 + ((j ^ swz128(row)) << 4)) = st.a[i];
         }
 #pragma unroll
         for (int i = 0; i < BPASS; ++i) {
             const int row = lrow + 32 * i;
-            *(uint4*)(Bs(buf) + row * 128 + ((j ^ swz128(row)) << 4)) = st.b[i];
+            *(uint4*)(Bs + row * 128 + ((j ^ swz128(row)) << 4)) = st.b[i];
         }
     };
 
     f32x4 acc[NI][MI];
-#pragma unroll
-    for (int a = 0; a < NI; ++a)
-#pragma unroll
-        for (int b = 0; b < MI; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int lr = lane & 15, g = lane >> 4;
-    const int sw = swz128(lr);
-    const int fo0 = ((2 * g) ^ sw) << 4, fo1 = ((2 * g + 1) ^ sw) << 4;
+    auto activate = [&](float (&v)[4]) {
+        if (p.act == ACT_RELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        } else if (p.act == ACT_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+        }
+    };
 
-    const int nk = p.Kp / BKE;
-    issue(0);
-    commit(0);
-    __syncthreads();
-    for (int ks = 0; ks < nk; ++ks) {
-        const int cur = ks & 1;
-        if (ks + 1 < nk) issue(ks + 1);
-        uint4 xf[MI][2], wf[NI][2];
+    // ---- epilogue of the tile at (em0, en0): lane holds channels n..n+3 (n = .. + 4g) of pixel m (= .. + lr)
+    auto epilogue = [&](int em0, int en0) {
+        if (p.epi_lds) {
+            // Coalesced path: bias / residual / activation in registers, tile -> LDS ([rows][BN] of the output type, 16-byte chunks
+            // XOR-swizzled by row), then every thread stores 16-byte chunks so a row segment leaves as one contiguous run.
+            const int osz = (p.out_f32 || sizeof(T) == 4) ? 4 : 2;
+            const int row_bytes = BN * osz;                    // 64..512, a power of two
+            const int cpr = row_bytes >> 4;                    // 16-byte chunks per row
+            const int passes = (BM * row_bytes + LDS_BYTES - 1) / LDS_BYTES;   // 1 or 2 (2: fp32 output of a 128-wide tile)
+            const int rows_pp = BM / passes;
+            for (int ps = 0; ps < passes; ++ps) {
+                __syncthreads();  // main loop (or previous pass) is done with the LDS
+                if ((wm * TM) / rows_pp == ps) {
+#pragma unroll
+                    for (int b = 0; b < MI; ++b) {
+                        const int rl = wm * TM + b * 16 + lr - ps * rows_pp;  // row inside this pass
+                        const int m = em0 + wm * TM + b * 16 + lr;
+                        const size_t rrow = (size_t)(m < p.M ? m : 0);
+#pragma unroll
+                        for (int a = 0; a < NI; ++a) {
+                            const int nl = wn * TN + a * 16 + 4 * g;  // column inside the tile
+                            const int n = en0 + nl;
+                            float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
+                            const int nglob = grp * p.N_g + (n < p.N_g ? n : 0);
+                            if (p.bias) {
+                                const float4 bv = *(const float4*)(p.bias + nglob);
+                                v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+                            }
+                            if (p.res_post) activate(v);
+                            if (p.res_mode == RES_SAME && m < p.M && n < p.N_g) {
+                                const size_t ro = rrow * p.ldr + nglob;
+                                if (p.res_f32) {
+                                    const float4 rv = *(const float4*)((const float*)p.res + ro);
+                                    v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+                                } else {
+                                    const T* rp = (const T*)p.res + ro;
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) v[r] += to_f32<T>(rp[r]);
+                                }
+                            }
+                            if (!p.res_post) activate(v);
+                            const int byte = nl * osz;
+                            char* dst = smem + rl * row_bytes + ((((byte >> 4) ^ rl) & (cpr - 1)) << 4) + (byte & 15);
+                            if (osz == 4) {
+                                *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+                            } else {
+                                union { T h[4]; uint2 u; } pk;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) pk.h[r] = from_f32<T>(v[r]);
+                                *(uint2*)dst = pk.u;
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+                const int nvalid_bytes = (min(BN, p.N_g - en0)) * osz;  // N tail of the last column tile (multiple of 16)
+                for (int idx = tid; idx < rows_pp * cpr; idx += 256) {
+                    const int rl = idx / cpr, c = idx - rl * cpr;
+                    const int m = em0 + ps * rows_pp + rl;
+                    if (m < p.M && (c << 4) < nvalid_bytes) {
+                        const uint4 val = *(const uint4*)(smem + rl * row_bytes + (((c ^ rl) & (cpr - 1)) << 4));
+                        char* o = (char*)p.out + ((size_t)m * p.ldo + p.out_coff + grp * p.N_g + en0) * osz + (c << 4);
+                        *(uint4*)o = val;
+                    }
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int b = 0; b < MI; ++b) {
-            const char* r = As(cur) + (wm * TM + b * 16 + lr) * 128;
-            xf[b][0] = *(const uint4*)(r + fo0);
-            xf[b][1] = *(const uint4*)(r + fo1);
-        }
+            const int m = em0 + wm * TM + b * 16 + lr;
+            if (m >= p.M) continue;
+            size_t orow = (size_t)m, rrow = 0;
+            if (p.store_mode == ST_SHUFFLE2 || p.res_mode == RES_UP2) {
+                const int t = fastdiv(m, p.mg_ow), ow = m - t * p.OW, img = fastdiv(t, p.mg_oh), oh = t - img * p.OH;
+                if (p.res_mode == RES_UP2) rrow = ((size_t)img * (p.OH >> 1) + (oh >> 1)) * (p.OW >> 1) + (ow >> 1);
+                if (p.store_mode == ST_SHUFFLE2) orow = ((size_t)img * (2 * p.OH) + 2 * oh) * (2 * p.OW) + 2 * ow;
+            }
+            if (p.res_mode == RES_SAME) rrow = (size_t)m;
 #pragma unroll
-        for (int a = 0; a < NI; ++a) {
-            const char* r = Bs(cur) + (wn * TN + a * 16 + lr) * 128;
-            wf[a][0] = *(const uint4*)(r + fo0);
-            wf[a][1] = *(const uint4*)(r + fo1);
+            for (int a = 0; a < NI; ++a) {
+                const int n = en0 + wn * TN + a * 16 + 4 * g;  // within group
+                if (n >= p.N_g) continue;
+                float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
+                const int nglob = grp * p.N_g + n;
+                if (p.store_mode == ST_DCN_OFFS) {
+                    float* o = (float*)p.out + orow * 32 + n;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int nn = n + r;
+                        float t = nn < p.N_g ? v[r] + p.bias[nn] : 0.f;
+                        if (nn >= 18) t = nn < p.N_g ? 1.0f / (1.0f + expf(-t)) : 0.f;  // mask = sigmoid (dcn.py:46)
+                        o[r] = t;
+                    }
+                    continue;
+                }
+                if (p.bias) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += p.bias[nglob + r];
+                }
+                if (p.res_post) activate(v);
+                if (p.res_mode != RES_NONE) {
+                    const size_t ro = rrow * p.ldr + nglob;
+                    if (p.res_f32) {
+                        const float4 rv = *(const float4*)((const float*)p.res + ro);
+                        v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+                    } else {
+                        const T* rp = (const T*)p.res + ro;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += to_f32<T>(rp[r]);
+                    }
+                }
+                if (!p.res_post) activate(v);
+                size_t oo;
+                if (p.store_mode == ST_SHUFFLE2) {
+                    const int ab = n / p.shuffle_co, co = n - ab * p.shuffle_co;
+                    oo = (orow + (size_t)(ab >> 1) * (2 * p.OW) + (ab & 1)) * p.ldo + p.out_coff + grp * p.shuffle_co + co;
+                } else {
+                    oo = orow * p.ldo + p.out_coff + nglob;
+                }
+                if (p.out_f32 || sizeof(T) == 4) {
+                    *(float4*)((float*)p.out + oo) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    union { T h[4]; uint2 u; } pk;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pk.h[r] = from_f32<T>(v[r]);
+                    *(uint2*)((T*)p.out + oo) = pk.u;
+                }
+            }
         }
+    };
+
+    // ---- persistent tile loop
+    int tile = xcd_remap(blockIdx.x, G);
+    if (tile >= total) return;
+    setup(tile);
+    issue(0);
+    commit();
+    __syncthreads();
+    for (;;) {
+        const int em0 = m0, en0 = n0;
+        const int next = tile + G;
+        const bool has_next = PERSIST && next < total;
 #pragma unroll
         for (int a = 0; a < NI; ++a)
 #pragma unroll
-            for (int b = 0; b < MI; ++b) Mma<T>::run(wf[a], xf[b], acc[a][b]);
-        if (ks + 1 < nk) commit(cur ^ 1);
+            for (int b = 0; b < MI; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < nk; ++ks) {
+            if (ks + 1 < nk) {
+                issue(ks + 1);
+            } else if (has_next) {  // cross the tile boundary: the next tile's first K-step flies during this tile's last MFMAs + epilogue
+                setup(next);
+                issue(0);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {  // the two 16-byte halves of this lane's 32-byte K slice
+                const int fo = h == 0 ? fo0 : fo1;
+                uint4 xf[MI], wf[NI];
+#pragma unroll
+                for (int b = 0; b < MI; ++b) xf[b] = *(const uint4*)(As + (wm * TM + b * 16 + lr) * 128 + fo);
+#pragma unroll
+                for (int a = 0; a < NI; ++a) wf[a] = *(const uint4*)(Bs + (wn * TN + a * 16 + lr) * 128 + fo);
+#pragma unroll
+                for (int a = 0; a < NI; ++a)
+#pragma unroll
+                    for (int b = 0; b < MI; ++b) Mma<T>::half(wf[a], xf[b], acc[a][b]);
+            }
+            if (ks + 1 < nk) {
+                __syncthreads();  // every wave is done reading the stage
+                commit();
+                __syncthreads();
+            }
+        }
+        epilogue(em0, en0);
+        if (!has_next) break;
+        __syncthreads();  // LDS (last K-step's operands, or the staged output tile) is free again
+        commit();
         __syncthreads();
-    }
-
-    // ---- epilogue: lane holds channels n..n+3 (n = .. + 4g) of pixel m (= .. + lr)
-#pragma unroll
-    for (int b = 0; b < MI; ++b) {
-        const int m = m0 + wm * TM + b * 16 + lr;
-        if (m >= p.M) continue;
-        size_t orow, rrow = 0;
-        if (p.store_mode == ST_SHUFFLE2 || p.res_mode == RES_UP2) {
-            const int ow = m % p.OW, t = m / p.OW, oh = t % p.OH, img = t / p.OH;
-            orow = (size_t)m;
-            if (p.res_mode == RES_UP2) rrow = ((size_t)img * (p.OH >> 1) + (oh >> 1)) * (p.OW >> 1) + (ow >> 1);
-            if (p.store_mode == ST_SHUFFLE2) orow = ((size_t)img * (2 * p.OH) + 2 * oh) * (2 * p.OW) + 2 * ow;
-        } else {
-            orow = (size_t)m;
-        }
-        if (p.res_mode == RES_SAME) rrow = (size_t)m;
-#pragma unroll
-        for (int a = 0; a < NI; ++a) {
-            const int n = n0 + wn * TN + a * 16 + 4 * g;  // within group
-            if (n >= p.N_g) continue;
-            float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
-            const int nglob = grp * p.N_g + n;
-            if (p.store_mode == ST_DCN_OFFS) {
-                float* o = (float*)p.out + orow * 32 + n;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int nn = n + r;
-                    float t = nn < p.N_g ? v[r] + p.bias[nn] : 0.f;
-                    if (nn >= 18) t = nn < p.N_g ? 1.0f / (1.0f + expf(-t)) : 0.f;  // mask = sigmoid (dcn.py:46)
-                    o[r] = t;
-                }
-                continue;
-            }
-            if (p.bias) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += p.bias[nglob + r];
-            }
-            if (p.res_post) {
-                if (p.act == ACT_RELU) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-                } else if (p.act == ACT_GELU) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-                }
-            }
-            if (p.res_mode != RES_NONE) {
-                const size_t ro = rrow * p.ldr + nglob;
-                if (p.res_f32) {
-                    const float4 rv = *(const float4*)((const float*)p.res + ro);
-                    v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
-                } else {
-                    const T* rp = (const T*)p.res + ro;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += to_f32<T>(rp[r]);
-                }
-            }
-            if (!p.res_post) {
-                if (p.act == ACT_RELU) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-                } else if (p.act == ACT_GELU) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-                }
-            }
-            size_t oo;
-            if (p.store_mode == ST_SHUFFLE2) {
-                const int ab = n / p.shuffle_co, co = n - ab * p.shuffle_co;
-                oo = (orow + (size_t)(ab >> 1) * (2 * p.OW) + (ab & 1)) * p.ldo + p.out_coff + grp * p.shuffle_co + co;
-            } else {
-                oo = orow * p.ldo + p.out_coff + nglob;
-            }
-            if (p.out_f32) {
-                *(float4*)((float*)p.out + oo) = make_float4(v[0], v[1], v[2], v[3]);
-            } else if constexpr (sizeof(T) == 4) {
-                *(float4*)((float*)p.out + oo) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-                union { T h[4]; uint2 u; } pk;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) pk.h[r] = from_f32<T>(v[r]);
-                *(uint2*)((T*)p.out + oo) = pk.u;
-            }
-        }
+        tile = next;
     }
 }
 

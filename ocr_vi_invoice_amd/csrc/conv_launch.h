@@ -1,22 +1,34 @@
 // launch_conv<T>: host-side validation + tile dispatch for conv_gemm_kernel.  Included by conv_{f32,bf16,f16}.hip
 // (one translation unit per dtype so they compile in parallel).
 #pragma once
+#include <stdlib.h>
+#include <string.h>
+
 #include "conv_gemm.h"
 
 namespace ocrvi {
 
 template <typename T, int AMODE, int BM, int BN, int WM, int WN>
 static int launch_tile(const ConvParams& p, hipStream_t stream) {
-    constexpr int smem = 2 * (BM + BN) * 128;
-    auto kern = conv_gemm_kernel<T, AMODE, BM, BN, WM, WN>;
-    static bool attr_done = false;  // one-time opt-in for > 48 KiB dynamic LDS
-    if (!attr_done) {
-        OCRVI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_done = true;
+    constexpr int smem = (BM + BN) * 128;
+    constexpr bool PERSIST = false;
+    auto kern = conv_gemm_kernel<T, AMODE, BM, BN, WM, WN, PERSIST>;
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        OCRVI_HIP(hipGetDevice(&dev));
+        OCRVI_HIP(hipGetDeviceProperties(&prop, dev));
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    const int mtiles = cdiv(p.M, BM), ntiles = p.Np / BN;
-    dim3 grid(mtiles * ntiles, p.groups);
-    hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, p);
+    // persistent grid: at most (resident workgroups per CU) x CUs, and balanced so every workgroup walks the same number of tiles
+    const int total = cdiv(p.M, BM) * (p.Np / BN);
+    int grid_x = total;
+    if (PERSIST) {  // balanced persistent grid: every workgroup walks the same number of tiles
+        const int gmax = n_cu * ConvOcc<AMODE, BM, BN>::value;
+        grid_x = cdiv(total, cdiv(total, gmax));
+    }
+    hipLaunchKernelGGL(kern, dim3(grid_x, p.groups), dim3(256), smem, stream, p);
     OCRVI_HIP(hipGetLastError());
     return OCRVI_OK;
 }
@@ -27,7 +39,7 @@ static int launch_mode(const ConvParams& p, hipStream_t stream) {
     OCRVI_CHECK(p.Np % bn == 0 && p.Np >= p.N_g, OCRVI_EINVAL, "conv: Np=%d not a multiple of BN=%d / < N_g=%d", p.Np, bn, p.N_g);
     if constexpr (AMODE == AM_DCN) {
         OCRVI_CHECK(bn == 128, OCRVI_EINVAL, "dcn: needs N_g > 64 (got %d)", p.N_g);
-        return launch_tile<T, AMODE, 128, 128, 2, 2>(p, stream);
+        return launch_tile<T, AMODE, 64, 128, 2, 2>(p, stream);  // 64-row tile: half the in-flight corner loads -> 3 waves/SIMD
     } else if constexpr (AMODE == AM_ROWS) {
         OCRVI_CHECK(bn <= 64, OCRVI_EINVAL, "rows-mode stem conv: N_g=%d > 64 unsupported", p.N_g);
         if (bn == 64) return launch_tile<T, AMODE, 128, 64, 2, 2>(p, stream);
@@ -40,8 +52,20 @@ static int launch_mode(const ConvParams& p, hipStream_t stream) {
 }
 
 template <typename T>
-int launch_conv(const ConvParams& p, int amode, hipStream_t stream) {
+int launch_conv(const ConvParams& p_in, int amode, hipStream_t stream) {
     constexpr int EPC = TypeInfo<T>::EPC, BKE = 8 * EPC;
+    ConvParams p = p_in;
+    OCRVI_CHECK(p.M > 0 && p.M < (1 << 23) && p.OW > 0 && p.OH > 0, OCRVI_EINVAL, "conv: M=%d outside (0, 2^23)", p.M);
+    p.mg_ow = ((1ull << 40) / (unsigned long long)p.OW) + 1;
+    p.mg_oh = ((1ull << 40) / (unsigned long long)p.OH) + 1;
+    p.identity_pix = (amode == AM_CONV1 && p.SH == 1 && p.SW == 1 && p.PH == 0 && p.PW == 0 && p.H == p.OH && p.W == p.OW &&
+                      p.store_mode == ST_NHWC && p.res_mode != RES_UP2) ? 1 : 0;
+    {   // coalesced LDS-staged epilogue whenever 16-byte row chunks are aligned (A/B switch: OCRVI_CONV_EPI=direct)
+        static const bool direct = getenv("OCRVI_CONV_EPI") && !strcmp(getenv("OCRVI_CONV_EPI"), "direct");
+        const int osz = (p.out_f32 || sizeof(T) == 4) ? 4 : 2, per = 16 / osz;
+        p.epi_lds = (!direct && p.store_mode == ST_NHWC && p.res_mode != RES_UP2 && p.N_g % per == 0 && p.ldo % per == 0 &&
+                     p.out_coff % per == 0 && ((uintptr_t)p.out & 15) == 0) ? 1 : 0;
+    }
     OCRVI_CHECK(p.x && p.w && p.out, OCRVI_EINVAL, "conv: null operand");
     OCRVI_CHECK(p.M > 0 && p.M == p.n_img * p.OH * p.OW, OCRVI_EINVAL, "conv: M=%d != %d*%d*%d", p.M, p.n_img, p.OH, p.OW);
     OCRVI_CHECK(p.Kp > 0 && p.Kp % BKE == 0, OCRVI_EINVAL, "conv: Kp=%d not a multiple of %d", p.Kp, BKE);

@@ -1,5 +1,6 @@
 // Host utilities: error string, blob parsing, dtype conversion, weight packing, dtype dispatch.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -185,7 +186,7 @@ static const char* amode_name(int amode, const ConvParams& p) {
 }
 
 int launch_conv_dt(int dtype, const ConvParams& p, int amode, hipStream_t stream) {
-    char tag[96];
+    char tag[160];
     double flops = 0, bytes = 0;
     if (g_prof_on) {
         const int ks = amode == AM_CONV1 ? 1 : (amode == AM_ROWS ? p.KH : 3);
@@ -196,7 +197,12 @@ int launch_conv_dt(int dtype, const ConvParams& p, int amode, hipStream_t stream
         bytes = (double)p.n_img * p.H * p.W * (amode == AM_ROWS ? 4 : p.Cin_g * p.groups) * esz + (double)p.N_g * p.groups * kvalid * esz +
                 (double)p.M * p.N_g * p.groups * (p.out_f32 ? 4.0 : esz) + (p.res ? (double)p.M * p.N_g * p.groups * (p.res_f32 ? 4.0 : esz) : 0.0) +
                 (p.offs ? (double)p.M * 27 * 4 : 0.0);
-        snprintf(tag, sizeof(tag), "%s_128x%d_%s", amode_name(amode, p), conv_bn_for(p.N_g), dtype_name(dtype));
+        static const bool detail = getenv("OCRVI_PROF_DETAIL") != nullptr;
+        if (detail)
+            snprintf(tag, sizeof(tag), "%s_%dx%d_%s M%d N%d K%d g%d s%d", amode_name(amode, p), amode == AM_DCN ? 64 : 128, conv_bn_for(p.N_g), dtype_name(dtype), p.M,
+                     p.N_g, (int)kvalid, p.groups, p.SH);
+        else
+            snprintf(tag, sizeof(tag), "%s_%dx%d_%s", amode_name(amode, p), amode == AM_DCN ? 64 : 128, conv_bn_for(p.N_g), dtype_name(dtype));
     }
     ProfScope ps(tag, flops, bytes, stream);
     switch (dtype) {

@@ -335,49 +335,68 @@ int k_asf(int dtype, const void* p2, const void* p3, const void* p4, const void*
 }
 
 // ------------------------------------------------------------------ DB head tail: deconv2 (64->1, 2x2 s2) x2 branches + sigmoid + step
+// 128/EPC lanes share one pixel's 128-channel row (one 16-byte chunk per lane -> the wave reads whole contiguous rows):
+// lanes of the first half own the binarise branch (ch 0..63), of the second the threshold branch.  Each lane keeps the
+// deconv weights of its own channels in registers, partial sums are butterflied inside the branch, and lanes 0..3 of a
+// pixel write the four 2x2 output positions.
 template <typename T>
 __global__ __launch_bounds__(256) void db_tail_kernel(const T* __restrict__ y, const float* __restrict__ w2, const float* __restrict__ b2, float k,
                                                       float* __restrict__ binary, float* __restrict__ thresh, float* __restrict__ tbin,
                                                       float* __restrict__ blog, float* __restrict__ tlog, int N, int H2, int W2) {
-    __shared__ float ws[2 * 64 * 4];
-    for (int i = threadIdx.x; i < 512; i += blockDim.x) ws[i] = w2[i];
-    __syncthreads();
     constexpr int EPC = TypeInfo<T>::EPC;
+    constexpr int LPP = 128 / EPC;      // lanes per pixel (16 or 32)
+    constexpr int PPW = 64 / LPP;       // pixels per wave pass
+    const int lane = threadIdx.x & 63;
+    const int j = lane % LPP, sub = lane / LPP;
+    const int br = j >= LPP / 2 ? 1 : 0;
+    float wr[EPC][4];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        const float4 t = *(const float4*)(w2 + (size_t)(j * EPC + e) * 4);  // w2 is [2][64][4] = [128][4] in channel order
+        wr[e][0] = t.x; wr[e][1] = t.y; wr[e][2] = t.z; wr[e][3] = t.w;
+    }
+    const float bias = b2[br];
     const size_t total = (size_t)N * H2 * W2;
+    const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nwaves = (size_t)gridDim.x * (blockDim.x >> 6);
     const int OW = 2 * W2;
-    for (size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pix < total; pix += (size_t)gridDim.x * blockDim.x) {
-        const int x = (int)(pix % W2);
-        const size_t t = pix / W2;
-        const int yy = (int)(t % H2), n = (int)(t / H2);
-        float lg[2][4];
+    for (size_t p0 = wave * PPW; p0 < total; p0 += nwaves * PPW) {
+        const size_t pix = p0 + sub;
+        const bool ok = pix < total;
+        float f[EPC];
+        uint4 raw = make_uint4(0, 0, 0, 0);
+        if (ok) raw = *(const uint4*)(y + pix * 128 + j * EPC);
+        Chunk<T>::unpack(raw, f);
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int br = 0; br < 2; ++br) {
-            float a[4] = {b2[br], b2[br], b2[br], b2[br]};
+        for (int e = 0; e < EPC; ++e) {
 #pragma unroll
-            for (int cc = 0; cc < 64 / EPC; ++cc) {
-                float f[EPC];
-                Chunk<T>::unpack(*(const uint4*)(y + pix * 128 + br * 64 + cc * EPC), f);
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) {
-                    const float4 wv = *(const float4*)(ws + (br * 64 + cc * EPC + e) * 4);
-                    a[0] = fmaf(f[e], wv.x, a[0]); a[1] = fmaf(f[e], wv.y, a[1]);
-                    a[2] = fmaf(f[e], wv.z, a[2]); a[3] = fmaf(f[e], wv.w, a[3]);
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) lg[br][q] = a[q];
+            for (int q = 0; q < 4; ++q) a[q] = fmaf(f[e], wr[e][q], a[q]);
         }
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const size_t o = ((size_t)n * (2 * H2) + 2 * yy + a) * OW + 2 * x;
-            const float l0 = lg[0][a * 2], l1 = lg[0][a * 2 + 1], t0 = lg[1][a * 2], t1 = lg[1][a * 2 + 1];
-            const float pb0 = 1.f / (1.f + expf(-l0)), pb1 = 1.f / (1.f + expf(-l1));
-            const float pt0 = 1.f / (1.f + expf(-t0)), pt1 = 1.f / (1.f + expf(-t1));
-            *(float2*)(binary + o) = make_float2(pb0, pb1);
-            if (thresh) *(float2*)(thresh + o) = make_float2(pt0, pt1);
-            if (tbin) *(float2*)(tbin + o) = make_float2(1.f / (1.f + expf(-k * (pb0 - pt0))), 1.f / (1.f + expf(-k * (pb1 - pt1))));
-            if (blog) *(float2*)(blog + o) = make_float2(l0, l1);
-            if (tlog) *(float2*)(tlog + o) = make_float2(t0, t1);
+        for (int o = 1; o < LPP / 2; o <<= 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[q] += __shfl_xor(a[q], o);
+        }
+        // every lane of a branch now holds that branch's 4 logits; fetch the other branch's from the partner half
+        float mine[4], other[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            mine[q] = a[q] + bias;
+            other[q] = __shfl_xor(mine[q], LPP / 2);
+        }
+        if (ok && j < 4) {  // lane j of the binarise half writes output position q = j
+            const float lb = j == 0 ? mine[0] : (j == 1 ? mine[1] : (j == 2 ? mine[2] : mine[3]));
+            const float lt = j == 0 ? other[0] : (j == 1 ? other[1] : (j == 2 ? other[2] : other[3]));
+            const int x = (int)(pix % W2);
+            const size_t t = pix / W2;
+            const int yy = (int)(t % H2), n = (int)(t / H2);
+            const size_t o = ((size_t)n * (2 * H2) + 2 * yy + (j >> 1)) * OW + 2 * x + (j & 1);
+            const float pb = 1.f / (1.f + expf(-lb)), pt = 1.f / (1.f + expf(-lt));
+            binary[o] = pb;
+            if (thresh) thresh[o] = pt;
+            if (tbin) tbin[o] = 1.f / (1.f + expf(-k * (pb - pt)));
+            if (blog) blog[o] = lb;
+            if (tlog) tlog[o] = lt;
         }
     }
 }
@@ -386,7 +405,7 @@ int k_db_tail(int dtype, const void* y, const float* w2, const float* b2, float 
     OCRVI_CHECK(y && w2 && b2 && binary && N > 0, OCRVI_EINVAL, "db tail: null operand");
     ProfScope ps_("db_head_tail", 0.0, (double)N*H2*W2*(128.0*dtype_size(dtype)+16.0*((thresh?1:0)+(thresh_binary?1:0)+(bin_logits?1:0)+(thresh_logits?1:0)+1)), s);
     const size_t total = (size_t)N * H2 * W2;
-    const int grid = (int)std::min<size_t>((total + 255) / 256, 256 * 16);
+    const int grid = (int)std::min<size_t>((total + 15) / 16, 256 * 8);
     DISPATCH_DT(dtype, hipLaunchKernelGGL(db_tail_kernel<T>, dim3(grid), dim3(256), 0, s, (const T*)y, w2, b2, k, binary, thresh, thresh_binary, bin_logits, thresh_logits, N, H2, W2));
     OCRVI_HIP(hipGetLastError());
     return OCRVI_OK;
