@@ -162,21 +162,8 @@ def main():
     rec_sd = weights.make_rec_state_dict("base", seed=1234)
     bcast_ms = None
     if world > 1:
-        flat = torch.cat([v.float().reshape(-1) for v in list(det_sd.values()) + list(rec_sd.values())]).to(dev)
-        if rank != 0:
-            flat.zero_()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        dist.broadcast(flat, 0)
-        torch.cuda.synchronize()
-        bcast_ms = (time.perf_counter() - t0) * 1e3
-        off = 0
-        flat = flat.cpu()
-        for sd in (det_sd, rec_sd):
-            for k, v in sd.items():
-                n = v.numel()
-                sd[k] = flat[off:off + n].reshape(v.shape).to(v.dtype)
-                off += n
+        from ocr_vi_invoice_amd.dist import broadcast_weights
+        bcast_ms = broadcast_weights([det_sd, rec_sd], dev, dist)
 
     # ---- synthetic inputs (this rank's shard)
     imgs, boxes = [], []
@@ -209,9 +196,8 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        from ocr_vi_invoice_amd.dist import max_over_ranks
+        dt = max_over_ranks(dt, dev, dist)
     prof = {}
     if not args.no_prof:
         _lib.check(lib.ocrvi_prof_enable(0))

@@ -110,3 +110,22 @@ def test_dbnet_shapes_and_param_count():
     for k in ("binary", "thresh", "thresh_binary"):
         assert out[k].shape == (1, 1, 64, 96)
         assert 0.0 <= float(out[k].min()) and float(out[k].max()) <= 1.0
+
+
+def test_preproc_oracle_known_answers():
+    """Hand-checkable cases of the cv2-style 8-bit bilinear resize restatement (oracle/preproc_cpu.py)."""
+    from oracle import preproc_cpu as P
+    flat = np.full((7, 13, 3), 200, np.uint8)
+    assert (P.resize_linear_u8(flat, (29, 48)) == 200).all()            # constant image stays constant
+    img = np.arange(4 * 6 * 3, dtype=np.uint8).reshape(4, 6, 3)
+    np.testing.assert_array_equal(P.resize_linear_u8(img, (6, 4)), img)  # identity scale
+    two = P.resize_linear_u8(img, (3, 2))                                # exact 2x decimation = 2x2 box mean, round half up
+    want = (img[0::2, 0::2].astype(int) + img[0::2, 1::2] + img[1::2, 0::2] + img[1::2, 1::2] + 2) >> 2
+    np.testing.assert_array_equal(two, want)
+    up = P.resize_linear_u8(np.array([[[0, 0, 0], [255, 255, 255]]], np.uint8), (4, 1))[0, :, 0]
+    assert list(up) == [0, 64, 191, 255]                                 # taps at -0.25, 0.25, 0.75, 1.25 -> weights .25/.75
+    crop = np.full((10, 40, 3), 255, np.uint8)
+    t = P.preprocess_for_recognition(crop, (32, 256))                    # new_w = int(40 * 3.2) = 128, right-padded with 255
+    assert t.shape == (3, 32, 256)
+    np.testing.assert_allclose(t[0], (1.0 - 0.485) / 0.229, rtol=1e-6)
+    assert (P.preprocess_for_recognition(np.zeros((0, 5, 3), np.uint8)) == 0).all()
