@@ -14,6 +14,8 @@
 //   AM_DCN               modulated deformable 3x3 (torchvision.ops.deform_conv2d as called in dcn.py:48-57):
 //                        4-corner bilinear gather of NHWC channel vectors, blended in fp32, written to LDS.
 #pragma once
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace ocrvi {
@@ -59,7 +61,10 @@ template <int AMODE, int BM, int BN> struct ConvOcc { static constexpr int value
 // PERSIST = false (shipped): one tile per workgroup.  Measured on MI355X (profiles/r01_conv_variants.md): holding the next
 // tile's loads across the epilogue costs ~40 VGPRs, i.e. one resident workgroup per CU, and loses 10-35 % on every shape;
 // occupancy (3-5 workgroups per CU) hides more latency than cross-tile prefetch does.
-template <typename T, int AMODE, int BM, int BN, int WM, int WN, bool PERSIST>
+// PERSIST: 0 = one tile per workgroup; 1 = persistent with cross-tile prefetch (next tile's loads issued before this tile's
+// epilogue; +~40 VGPRs); 2 = persistent, tiles strictly one after another (no extra registers; tile i's stores drain under
+// tile i+1's loads).
+template <typename T, int AMODE, int BM, int BN, int WM, int WN, int PERSIST>
 __global__ __launch_bounds__(256, (ConvOcc<AMODE, BM, BN>::value)) void conv_gemm_kernel(const ConvParams p) {
     constexpr int EPC = TypeInfo<T>::EPC;  // elements per 16-byte chunk
     constexpr int BKE = 8 * EPC;           // elements per K-step (128 bytes)
@@ -378,7 +383,7 @@ __global__ __launch_bounds__(256, (ConvOcc<AMODE, BM, BN>::value)) void conv_gem
     for (;;) {
         const int em0 = m0, en0 = n0;
         const int next = tile + G;
-        const bool has_next = PERSIST && next < total;
+        const bool has_next = PERSIST == 1 && next < total;
 #pragma unroll
         for (int a = 0; a < NI; ++a)
 #pragma unroll
@@ -410,6 +415,16 @@ __global__ __launch_bounds__(256, (ConvOcc<AMODE, BM, BN>::value)) void conv_gem
             }
         }
         epilogue(em0, en0);
+        if constexpr (PERSIST == 2) {
+            if (next >= total) break;
+            setup(next);
+            issue(0);         // the stores of the tile just finished are still draining
+            __syncthreads();  // LDS (staged output tile) is free again
+            commit();
+            __syncthreads();
+            tile = next;
+            continue;
+        }
         if (!has_next) break;
         __syncthreads();  // LDS (last K-step's operands, or the staged output tile) is free again
         commit();
@@ -419,7 +434,11 @@ __global__ __launch_bounds__(256, (ConvOcc<AMODE, BM, BN>::value)) void conv_gem
 }
 
 // Tile choice shared by the packer (host) and the launcher.
-static inline int conv_bn_for(int n_g) { return n_g > 64 ? 128 : (n_g > 32 ? 64 : 32); }
+static inline int conv_bn_for(int n_g) {
+    static const int cap = getenv("OCRVI_CONV_BN") ? atoi(getenv("OCRVI_CONV_BN")) : 128;  // experiment knob (packing + launch agree)
+    const int bn = n_g > 64 ? 128 : (n_g > 32 ? 64 : 32);
+    return bn > cap ? cap : bn;
+}
 static inline int conv_bke(int dtype) { return dtype == OCRVI_F32 ? 32 : 64; }
 
 template <typename T> int launch_conv(const ConvParams& p, int amode, hipStream_t stream);

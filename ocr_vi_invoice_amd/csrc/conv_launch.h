@@ -11,8 +11,9 @@ namespace ocrvi {
 template <typename T, int AMODE, int BM, int BN, int WM, int WN>
 static int launch_tile(const ConvParams& p, hipStream_t stream) {
     constexpr int smem = (BM + BN) * 128;
-    constexpr bool PERSIST = false;
-    auto kern = conv_gemm_kernel<T, AMODE, BM, BN, WM, WN, PERSIST>;
+    static const int persist = getenv("OCRVI_CONV_PERSIST") ? atoi(getenv("OCRVI_CONV_PERSIST")) : 0;  // experiment knob
+    void (*kern)(const ConvParams) = persist == 2 ? conv_gemm_kernel<T, AMODE, BM, BN, WM, WN, 2> : conv_gemm_kernel<T, AMODE, BM, BN, WM, WN, 0>;
+    static const int tiles_per_wg = getenv("OCRVI_CONV_TPW") ? atoi(getenv("OCRVI_CONV_TPW")) : 4;
     static int n_cu = 0;
     if (!n_cu) {
         int dev = 0;
@@ -24,9 +25,11 @@ static int launch_tile(const ConvParams& p, hipStream_t stream) {
     // persistent grid: at most (resident workgroups per CU) x CUs, and balanced so every workgroup walks the same number of tiles
     const int total = cdiv(p.M, BM) * (p.Np / BN);
     int grid_x = total;
-    if (PERSIST) {  // balanced persistent grid: every workgroup walks the same number of tiles
-        const int gmax = n_cu * ConvOcc<AMODE, BM, BN>::value;
-        grid_x = cdiv(total, cdiv(total, gmax));
+    if (persist == 2) {  // every workgroup walks `tiles_per_wg` tiles (fewer when the grid would not fill the chip)
+        const int gmin = n_cu * ConvOcc<AMODE, BM, BN>::value;
+        int tpw = tiles_per_wg;
+        while (tpw > 1 && cdiv(total, tpw) < gmin) --tpw;
+        grid_x = cdiv(total, tpw);
     }
     hipLaunchKernelGGL(kern, dim3(grid_x, p.groups), dim3(256), smem, stream, p);
     OCRVI_HIP(hipGetLastError());
