@@ -46,6 +46,7 @@ struct ConvParams {
     unsigned long long mg_ow = 0, mg_oh = 0;  // floor(2^40/d)+1: n/d == (n*mg)>>40 for n < 2^23 (filled by launch_conv)
     int identity_pix = 0;  // 1x1, stride 1, pad 0: input pixel index == m (no decomposition needed)
     int epi_lds = 0;       // stage the output tile through LDS and store whole rows (ST_NHWC only; set by launch_conv)
+    int res_in_store = 0;  // fp32 out + fp32 residual, no activation: add the residual in the coalesced store phase
 };
 
 __device__ __forceinline__ int fastdiv(int n, unsigned long long mg) { return (int)(((unsigned long long)(unsigned)n * mg) >> 40); }
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(256, (ConvOcc<AMODE, BM, BN>::value)) void conv_gem
                                 v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
                             }
                             if (p.res_post) activate(v);
-                            if (p.res_mode == RES_SAME && m < p.M && n < p.N_g) {
+                            if (p.res_mode == RES_SAME && !p.res_in_store && m < p.M && n < p.N_g) {
                                 const size_t ro = rrow * p.ldr + nglob;
                                 if (p.res_f32) {
                                     const float4 rv = *(const float4*)((const float*)p.res + ro);
@@ -301,7 +302,14 @@ __global__ __launch_bounds__(256, (ConvOcc<AMODE, BM, BN>::value)) void conv_gem
                     const int rl = idx / cpr, c = idx - rl * cpr;
                     const int m = em0 + ps * rows_pp + rl;
                     if (m < p.M && (c << 4) < nvalid_bytes) {
-                        const uint4 val = *(const uint4*)(smem + rl * row_bytes + (((c ^ rl) & (cpr - 1)) << 4));
+                        uint4 val = *(const uint4*)(smem + rl * row_bytes + (((c ^ rl) & (cpr - 1)) << 4));
+                        if (p.res_in_store) {  // x += ...: whole-row float4 reads of the fp32 residual stream
+                            const float4 rv = *(const float4*)((const char*)p.res + ((size_t)m * p.ldr + grp * p.N_g + en0) * 4 + (c << 4));
+                            val.x = __float_as_uint(__uint_as_float(val.x) + rv.x);
+                            val.y = __float_as_uint(__uint_as_float(val.y) + rv.y);
+                            val.z = __float_as_uint(__uint_as_float(val.z) + rv.z);
+                            val.w = __float_as_uint(__uint_as_float(val.w) + rv.w);
+                        }
                         char* o = (char*)p.out + ((size_t)m * p.ldo + p.out_coff + grp * p.N_g + en0) * osz + (c << 4);
                         *(uint4*)o = val;
                     }

@@ -68,6 +68,8 @@ int launch_conv(const ConvParams& p_in, int amode, hipStream_t stream) {
         const int osz = (p.out_f32 || sizeof(T) == 4) ? 4 : 2, per = 16 / osz;
         p.epi_lds = (!direct && p.store_mode == ST_NHWC && p.res_mode != RES_UP2 && p.N_g % per == 0 && p.ldo % per == 0 &&
                      p.out_coff % per == 0 && ((uintptr_t)p.out & 15) == 0) ? 1 : 0;
+        p.res_in_store = (p.epi_lds && p.res_mode == RES_SAME && osz == 4 && (p.res_f32 || sizeof(T) == 4) && p.act == ACT_NONE &&
+                          p.ldr % 4 == 0 && ((uintptr_t)p.res & 15) == 0) ? 1 : 0;
     }
     OCRVI_CHECK(p.x && p.w && p.out, OCRVI_EINVAL, "conv: null operand");
     OCRVI_CHECK(p.M > 0 && p.M == p.n_img * p.OH * p.OW, OCRVI_EINVAL, "conv: M=%d != %d*%d*%d", p.M, p.n_img, p.OH, p.OW);
