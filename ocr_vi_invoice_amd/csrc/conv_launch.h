@@ -42,7 +42,10 @@ static int launch_mode(const ConvParams& p, hipStream_t stream) {
     OCRVI_CHECK(p.Np % bn == 0 && p.Np >= p.N_g, OCRVI_EINVAL, "conv: Np=%d not a multiple of BN=%d / < N_g=%d", p.Np, bn, p.N_g);
     if constexpr (AMODE == AM_DCN) {
         OCRVI_CHECK(bn == 128, OCRVI_EINVAL, "dcn: needs N_g > 64 (got %d)", p.N_g);
-        return launch_tile<T, AMODE, 64, 128, 2, 2>(p, stream);  // 64-row tile: half the in-flight corner loads -> 3 waves/SIMD
+        // 64-row tiles (half the in-flight corner loads); 256-wide N tiles when C_out allows so the gathered + blended A rows are
+        // shared by twice as many output channels (the blend is the VALU bottleneck of this kernel)
+        if (p.Np % 256 == 0) return launch_tile<T, AMODE, 64, 256, 2, 2>(p, stream);
+        return launch_tile<T, AMODE, 64, 128, 2, 2>(p, stream);
     } else if constexpr (AMODE == AM_ROWS) {
         OCRVI_CHECK(bn <= 64, OCRVI_EINVAL, "rows-mode stem conv: N_g=%d > 64 unsupported", p.N_g);
         if (bn == 64) return launch_tile<T, AMODE, 128, 64, 2, 2>(p, stream);
@@ -59,6 +62,7 @@ int launch_conv(const ConvParams& p_in, int amode, hipStream_t stream) {
     constexpr int EPC = TypeInfo<T>::EPC, BKE = 8 * EPC;
     ConvParams p = p_in;
     OCRVI_CHECK(p.M > 0 && p.M < (1 << 23) && p.OW > 0 && p.OH > 0, OCRVI_EINVAL, "conv: M=%d outside (0, 2^23)", p.M);
+    p.dbg = getenv("OCRVI_CONV_DBG") ? atoi(getenv("OCRVI_CONV_DBG")) : 0;
     p.mg_ow = ((1ull << 40) / (unsigned long long)p.OW) + 1;
     p.mg_oh = ((1ull << 40) / (unsigned long long)p.OH) + 1;
     p.identity_pix = (amode == AM_CONV1 && p.SH == 1 && p.SW == 1 && p.PH == 0 && p.PW == 0 && p.H == p.OH && p.W == p.OW &&

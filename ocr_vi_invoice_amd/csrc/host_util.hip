@@ -199,10 +199,10 @@ int launch_conv_dt(int dtype, const ConvParams& p, int amode, hipStream_t stream
                 (p.offs ? (double)p.M * 27 * 4 : 0.0);
         static const bool detail = getenv("OCRVI_PROF_DETAIL") != nullptr;
         if (detail)
-            snprintf(tag, sizeof(tag), "%s_%dx%d_%s M%d N%d K%d g%d s%d", amode_name(amode, p), amode == AM_DCN ? 64 : 128, conv_bn_for(p.N_g), dtype_name(dtype), p.M,
+            snprintf(tag, sizeof(tag), "%s_%dx%d_%s M%d N%d K%d g%d s%d", amode_name(amode, p), amode == AM_DCN ? 64 : 128, (amode == AM_DCN && p.Np % 256 == 0) ? 256 : conv_bn_for(p.N_g), dtype_name(dtype), p.M,
                      p.N_g, (int)kvalid, p.groups, p.SH);
         else
-            snprintf(tag, sizeof(tag), "%s_%dx%d_%s", amode_name(amode, p), amode == AM_DCN ? 64 : 128, conv_bn_for(p.N_g), dtype_name(dtype));
+            snprintf(tag, sizeof(tag), "%s_%dx%d_%s", amode_name(amode, p), amode == AM_DCN ? 64 : 128, (amode == AM_DCN && p.Np % 256 == 0) ? 256 : conv_bn_for(p.N_g), dtype_name(dtype));
     }
     ProfScope ps(tag, flops, bytes, stream);
     switch (dtype) {
