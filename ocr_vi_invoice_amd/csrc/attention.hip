@@ -32,7 +32,9 @@ template <> __device__ __forceinline__ f32x4 mfma16<f16_t>(const uint4& a, const
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-template <typename T, int MAXT>
+// MAXT = number of 16-key tiles held in registers; MASK = false when N == 16*MAXT exactly (480 / 240 / 80 tokens at 48x320 input):
+// then no key masking is generated at all.
+template <typename T, int MAXT, bool MASK>
 __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int N, int heads) {
     constexpr int EPC = TypeInfo<T>::EPC;
     constexpr int KROW = AttnCfg<T>::KROW;
@@ -40,7 +42,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int h = blockIdx.x, b = blockIdx.y;
     const int D = heads * 32, ld = 3 * D;
-    constexpr int NP = MAXT * 16;  // keys padded to the variant's tile count (zero-filled, masked to -inf below)
+    constexpr int NP = ((MAXT + 1) / 2) * 32;  // key rows staged in LDS: whole 32-key PV steps (zero-filled past N)
     constexpr int VS = AttnCfg<T>::vstride(NP);
     char* Ks = smem;
     char* Vt = smem + (size_t)NP * KROW;
@@ -71,6 +73,12 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
         const int q = qt * 16 + lr;
         const bool qok = q < N;
         f32x4 acc[MAXT];
+        // K / V^T fragments are invariant across q-tiles; left alone, the compiler hoists all of them into registers (240 VGPRs at
+        // 480 keys -> 1 wave per SIMD).  An opaque zero offset per q-tile keeps them as LDS reads inside the loop.
+        int lds_off = 0;
+        if (MAXT > 8) asm volatile("" : "+v"(lds_off));
+        const char* Ksq = Ks + lds_off;
+        const char* Vtq = Vt + lds_off;
         if constexpr (sizeof(T) == 4) {
             uint4 qf[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
             if (qok) {
@@ -82,7 +90,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
 #pragma unroll
             for (int t = 0; t < MAXT; ++t) {
                 acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                const char* kr = Ks + (t * 16 + lr) * KROW;
+                const char* kr = Ksq + (t * 16 + lr) * KROW;
                 const uint4 kf[2] = {*(const uint4*)(kr + o0), *(const uint4*)(kr + o1)};
                 Mma<float>::run(kf, qf, acc[t]);
             }
@@ -93,44 +101,46 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
 #pragma unroll
             for (int t = 0; t < MAXT; ++t) {
                 acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                acc[t] = mfma16<T>(*(const uint4*)(Ks + (t * 16 + lr) * KROW + o0), qf, acc[t]);
+                acc[t] = mfma16<T>(*(const uint4*)(Ksq + (t * 16 + lr) * KROW + o0), qf, acc[t]);
             }
         }
         // ---- softmax over keys (this lane: keys 16t + 4g + r of query lr)
         float mx = -INFINITY;
-        int nlim = N - 4 * g;
-        asm volatile("" : "+v"(nlim));  // opaque per q-tile: stops LICM from hoisting 4*MAXT compare masks into (spilled) SGPRs
+        if constexpr (MASK) {
+            int nlim = N - 4 * g;
+            asm volatile("" : "+v"(nlim));  // opaque per q-tile: stops LICM from hoisting 4*MAXT compare masks into (spilled) SGPRs
 #pragma unroll
-        for (int t = 0; t < MAXT; ++t) {
+            for (int t = 0; t < MAXT; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                acc[t][r] = (t * 16 + r >= nlim) ? -INFINITY : acc[t][r];
-                mx = fmaxf(mx, acc[t][r]);
-            }
+                for (int r = 0; r < 4; ++r) acc[t][r] = (t * 16 + r >= nlim) ? -INFINITY : acc[t][r];
         }
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc[t][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 16));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float nm = -mx * c2;
         float sum = 0.f;
 #pragma unroll
         for (int t = 0; t < MAXT; ++t) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = exp2f((acc[t][r] - mx) * c2);
+                // exp2((s - max) * scale*log2e): one fma + raw v_exp_f32 (argument <= 0: no overflow; underflow flushes to 0)
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[t][r], c2, nm));
                 acc[t][r] = p;
-                sum += p;
+                if constexpr (sizeof(T) == 4) sum += p;
             }
         }
-        sum += __shfl_xor(sum, 16);
-        sum += __shfl_xor(sum, 32);
-        const float inv = 1.f / sum;
         // ---- O^T = V^T P^T
         f32x4 o[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+        f32x4 osum = (f32x4){0.f, 0.f, 0.f, 0.f};  // 16-bit modes: row sums by MFMA against a ones fragment
         if constexpr (sizeof(T) == 4) {
 #pragma unroll
             for (int t = 0; t < MAXT; ++t) {
 #pragma unroll
                     for (int dt = 0; dt < 2; ++dt) {
-                        const float4 vf = *(const float4*)(Vt + (dt * 16 + lr) * VS + (t * 16 + 4 * g) * 4);
+                        const float4 vf = *(const float4*)(Vtq + (dt * 16 + lr) * VS + (t * 16 + 4 * g) * 4);
                         o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.x, acc[t][0], o[dt], 0, 0, 0);
                         o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.y, acc[t][1], o[dt], 0, 0, 0);
                         o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.z, acc[t][2], o[dt], 0, 0, 0);
@@ -138,23 +148,35 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
                     }
                 }
         } else {
+            const T one = from_f32<T>(1.0f);
+            union { T e[8]; uint4 u; } ones;
 #pragma unroll
-            for (int s = 0; s < MAXT / 2; ++s) {
+            for (int r = 0; r < 8; ++r) ones.e[r] = one;
+#pragma unroll
+            for (int s = 0; s < (MAXT + 1) / 2; ++s) {
                     // B operand k-slot (g, j): key 32s + 16*(j>>2) + 4g + (j&3)  <-> accumulators of tiles 2s, 2s+1
                     union { T e[8]; uint4 u; } pf;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         pf.e[r] = from_f32<T>(acc[2 * s][r]);
-                        pf.e[4 + r] = from_f32<T>(acc[2 * s + 1][r]);
+                        pf.e[4 + r] = (2 * s + 1 < MAXT) ? from_f32<T>(acc[2 * s + 1 < MAXT ? 2 * s + 1 : 0][r]) : from_f32<T>(0.f);
                     }
+                    osum = mfma16<T>(ones.u, pf.u, osum);  // every row of osum = sum_k P[k][q] (of the ROUNDED P that PV uses)
 #pragma unroll
                     for (int dt = 0; dt < 2; ++dt) {
-                        const char* vr = Vt + (dt * 16 + lr) * VS + (32 * s + 4 * g) * 2;
+                        const char* vr = Vtq + (dt * 16 + lr) * VS + (32 * s + 4 * g) * 2;
                         const uint2 lo = *(const uint2*)vr, hi = *(const uint2*)(vr + 32);
                         o[dt] = mfma16<T>(make_uint4(lo.x, lo.y, hi.x, hi.y), pf.u, o[dt]);
                     }
                 }
         }
+        if constexpr (sizeof(T) == 4) {
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+        } else {
+            sum = osum[0];
+        }
+        const float inv = 1.f / sum;
         if (qok) {
             T* orow = out + ((size_t)b * N + q) * D + h * 32 + 4 * g;
 #pragma unroll
@@ -172,12 +194,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
     }
 }
 
-template <typename T, int MAXT>
-static int launch_attn(const void* qkv, void* out, int B, int N, int heads, hipStream_t s) {
-    static_assert(MAXT % 2 == 0, "16-bit PV consumes key tiles in pairs");
-    constexpr int NP = MAXT * 16;
+template <typename T, int MAXT, bool MASK>
+static int launch_attn_m(const void* qkv, void* out, int B, int N, int heads, hipStream_t s) {
+    constexpr int NP = ((MAXT + 1) / 2) * 32;
     const int smem = NP * AttnCfg<T>::KROW + 32 * AttnCfg<T>::vstride(NP);
-    auto kern = attention_kernel<T, MAXT>;
+    auto kern = attention_kernel<T, MAXT, MASK>;
     static bool attr_done = false;
     if (!attr_done) {
         OCRVI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -188,13 +209,20 @@ static int launch_attn(const void* qkv, void* out, int B, int N, int heads, hipS
     return OCRVI_OK;
 }
 
+template <typename T, int MAXT>
+static int launch_attn(const void* qkv, void* out, int B, int N, int heads, hipStream_t s) {
+    if (N == MAXT * 16) return launch_attn_m<T, MAXT, false>(qkv, out, B, N, heads, s);
+    return launch_attn_m<T, MAXT, true>(qkv, out, B, N, heads, s);
+}
+
 template <typename T>
 static int attn_dt(const void* qkv, void* out, int B, int N, int heads, hipStream_t s) {
     const int NT = (N + 15) >> 4;
-    if (NT <= 4) return launch_attn<T, 4>(qkv, out, B, N, heads, s);
-    if (NT <= 6) return launch_attn<T, 6>(qkv, out, B, N, heads, s);   // FRM rows, W/4 = 80
-    if (NT <= 8) return launch_attn<T, 8>(qkv, out, B, N, heads, s);
-    if (NT <= 16) return launch_attn<T, 16>(qkv, out, B, N, heads, s); // stage 2, 240 tokens
+    if (NT <= 4) return launch_attn<T, 4>(qkv, out, B, N, heads, s);   // 32x256 input: FRM rows, W/4 = 64
+    if (NT <= 5) return launch_attn<T, 5>(qkv, out, B, N, heads, s);   // FRM rows, W/4 = 80
+    if (NT <= 8) return launch_attn<T, 8>(qkv, out, B, N, heads, s);   // 32x256 input: stage 2, 128 tokens
+    if (NT <= 15) return launch_attn<T, 15>(qkv, out, B, N, heads, s); // stage 2, 240 tokens
+    if (NT <= 16) return launch_attn<T, 16>(qkv, out, B, N, heads, s); // 32x256 input: stage 1, 256 tokens
     if (NT <= 30) return launch_attn<T, 30>(qkv, out, B, N, heads, s); // stage 1, 480 tokens
     return launch_attn<T, 32>(qkv, out, B, N, heads, s);
 }
