@@ -23,13 +23,16 @@ namespace ocrvi {
 enum { AM_CONV1 = 0, AM_CONV3 = 1, AM_ROWS = 2, AM_DCN = 3 };
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
 enum { RES_NONE = 0, RES_SAME = 1, RES_UP2 = 2 };        // RES_UP2: nearest 2x upsample of a half-res tensor (neck.py:36-38)
-enum { ST_NHWC = 0, ST_SHUFFLE2 = 1, ST_DCN_OFFS = 2 };  // ST_SHUFFLE2: ConvTranspose2d(k=2,s=2) pixel shuffle (head.py:13,16)
+enum { ST_NHWC = 0, ST_SHUFFLE2 = 1, ST_DCN_OFFS = 2, ST_DB_TAIL = 3 };  // ST_SHUFFLE2: ConvTranspose2d(k=2,s=2) pixel shuffle (head.py:13,16)
+// ST_DB_TAIL: ST_SHUFFLE2 (64 ch, +bias, ReLU) followed IN THE EPILOGUE by the next ConvTranspose2d(64,1,2,2) (head.py:16): the wave's 64
+// columns are all channels of one sub-pixel, so the 64->1 deconv is an in-register dot + butterfly; writes fp32 logit maps [n,1,4*OH,4*OW].
 
 struct ConvParams {
     const void* x = nullptr;      // T   [n_img][H][W][Cin]   (AM_ROWS: [n_img][Hp][Wp][4])
     const void* w = nullptr;      // T   [groups][Np][Kp]
     const float* bias = nullptr;  // f32 [groups*N_g] or null
     void* out = nullptr;          // T or f32
+    void* out2 = nullptr;         // ST_DB_TAIL: logit map of group 1 (threshold branch); `out` is group 0's
     const void* res = nullptr;    // T or f32, or null
     const float* offs = nullptr;  // AM_DCN: f32 [M][32] = 18 offsets (dy,dx per tap), 9 sigmoided masks, 5 pad
     int n_img = 1, H = 1, W = 1, Cin = 0;
@@ -322,6 +325,42 @@ __global__ __launch_bounds__(256, (ConvOcc<AMODE, BM, BN>::value)) void conv_gem
                 }
             }
             return;
+        }
+        if constexpr (TN == 64) {
+            if (p.store_mode == ST_DB_TAIL) {
+                const float* w2 = p.offs + grp * 256;    // [64][4] second-deconv weights of this branch (c_in, a'b')
+                const float b2 = p.offs[512 + grp];
+                float* map = grp == 0 ? (float*)p.out : (float*)p.out2;
+                const int ab = (en0 + wn * TN) >> 6;     // this wave's sub-pixel (a, b) of the first deconv
+#pragma unroll
+                for (int b = 0; b < MI; ++b) {
+                    const int m = em0 + wm * TM + b * 16 + lr;
+                    float q[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int a = 0; a < NI; ++a) {
+                        const int n = en0 + wn * TN + a * 16 + 4 * g;
+                        const int co = n & 63;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float v = fmaxf(acc[a][b][r] + p.bias[grp * p.N_g + n + r], 0.f);   // deconv1 + BN + ReLU
+                            const float4 wv = *(const float4*)(w2 + (co + r) * 4);
+                            q[0] = fmaf(v, wv.x, q[0]); q[1] = fmaf(v, wv.y, q[1]); q[2] = fmaf(v, wv.z, q[2]); q[3] = fmaf(v, wv.w, q[3]);
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        q[i] += __shfl_xor(q[i], 16);
+                        q[i] += __shfl_xor(q[i], 32);
+                    }
+                    if (m < p.M) {  // lane group g writes output sub-position (a', b') = (g>>1, g&1)
+                        const int t = fastdiv(m, p.mg_ow), ow = m - t * p.OW, img = fastdiv(t, p.mg_oh), oh = t - img * p.OH;
+                        const float val = (g == 0 ? q[0] : (g == 1 ? q[1] : (g == 2 ? q[2] : q[3]))) + b2;
+                        const size_t row = (size_t)img * (4 * p.OH) + 4 * oh + 2 * (ab >> 1) + (g >> 1);
+                        map[row * (4 * p.OW) + 4 * ow + 2 * (ab & 1) + (g & 1)] = val;
+                    }
+                }
+                return;
+            }
         }
 #pragma unroll
         for (int b = 0; b < MI; ++b) {

@@ -80,7 +80,10 @@ int launch_conv(const ConvParams& p_in, int amode, hipStream_t stream) {
     OCRVI_CHECK(p.Kp > 0 && p.Kp % BKE == 0, OCRVI_EINVAL, "conv: Kp=%d not a multiple of %d", p.Kp, BKE);
     OCRVI_CHECK(p.groups >= 1 && p.N_g >= 1, OCRVI_EINVAL, "conv: bad groups/N");
     OCRVI_CHECK((size_t)p.M * (size_t)(p.ldo > 32 ? p.ldo : 32) < ((size_t)1 << 40), OCRVI_EINVAL, "conv: output too large");
-    if (p.store_mode != ST_DCN_OFFS) {
+    if (p.store_mode == ST_DB_TAIL) {
+        OCRVI_CHECK(amode == AM_CONV1 && p.shuffle_co == 64 && p.N_g == 256 && p.Np == 256 && p.out2 && p.offs && p.bias && p.groups == 2,
+                    OCRVI_EINVAL, "db-tail deconv: needs 2 groups of 4x64 columns, both logit maps and the second-deconv weights");
+    } else if (p.store_mode != ST_DCN_OFFS) {
         OCRVI_CHECK(p.N_g % 4 == 0 && p.ldo % 4 == 0 && p.out_coff % 4 == 0, OCRVI_EINVAL,
                     "conv: N_g=%d ldo=%d coff=%d must be multiples of 4", p.N_g, p.ldo, p.out_coff);
     } else {

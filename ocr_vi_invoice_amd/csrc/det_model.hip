@@ -27,7 +27,7 @@ struct ocrvi_det {
     ConvLayer lat[4], fpn[4];
     float *asf_w = nullptr, *asf_b = nullptr;
     ConvLayer head_conv, head_dc1;
-    float *dc2_w = nullptr, *dc2_b = nullptr;
+    float* dc2_wb = nullptr;  // [2][64][4] second-deconv weights followed by the 2 biases
     Tensor tap_c[4], tap_fused;
 };
 
@@ -96,8 +96,8 @@ extern "C" int ocrvi_det_create(int device, const void* blob_p, size_t blob_byte
         }
         OCRVI_TRY(upload_packed(st, both, AM_CONV1, &h->head_dc1));
         h->head_dc1.shuffle_co = 64;
-        OCRVI_TRY(st.upload_f32(w2, &h->dc2_w));
-        OCRVI_TRY(st.upload_f32(b2, &h->dc2_b));
+        w2.insert(w2.end(), b2.begin(), b2.end());
+        OCRVI_TRY(st.upload_f32(w2, &h->dc2_wb));
     }
     *out = h.release();
     return OCRVI_OK;
@@ -198,7 +198,8 @@ static int det_run(ocrvi_det* h, Runner& r, const float* x, int N, int H, int W,
     }
     // ---- adaptive scale fusion (neck.py:57-79)
     Tensor fused = r.alloc(N, p[0].h, p[0].w, 256);
-    if (!r.dry()) OCRVI_TRY(k_asf(dt, p[0].p, p[1].p, p[2].p, p[3].p, h->asf_w, h->asf_b, fused.p, N, p[0].h, p[0].w, r.stream));
+    float* asf_scratch = (float*)r.arena.alloc(asf_scratch_bytes(N, p[0].h, p[0].w));
+    if (!r.dry()) OCRVI_TRY(k_asf(dt, p[0].p, p[1].p, p[2].p, p[3].p, h->asf_w, h->asf_b, asf_scratch, fused.p, N, p[0].h, p[0].w, r.stream));
     h->tap_fused = fused;
     // ---- DB head (head.py:32-48): both branches' 3x3 convs as one 256->128 conv, both deconv1 as one grouped pixel-shuffle GEMM
     Tensor hc = r.alloc(N, fused.h, fused.w, 128);
@@ -207,14 +208,17 @@ static int det_run(ocrvi_det* h, Runner& r, const float* x, int N, int H, int W,
         o.pad = 1; o.act = ACT_RELU;
         OCRVI_TRY(conv(r, h->head_conv, fused, hc, o));
     }
-    Tensor d1 = r.alloc(N, 2 * fused.h, 2 * fused.w, 128);
+    // deconv1 (+BN+ReLU) and deconv2 (64 -> 1) of both branches in ONE GEMM: the 1.26 GB deconv1 activation is never materialised
+    const size_t map_elems = (size_t)N * H * W;
+    float* bl = blog ? blog : (float*)r.arena.alloc(map_elems * 4);
+    float* tl = tlog ? tlog : (float*)r.arena.alloc(map_elems * 4);
     {
+        Tensor lm; lm.p = bl; lm.n = N; lm.h = H; lm.w = W; lm.c = 1; lm.f32 = true;
         ConvOpts o;
-        o.act = ACT_RELU; o.store_mode = ST_SHUFFLE2;
-        OCRVI_TRY(conv(r, h->head_dc1, hc, d1, o));
+        o.store_mode = ST_DB_TAIL; o.out2 = tl; o.offs = h->dc2_wb;
+        OCRVI_TRY(conv(r, h->head_dc1, hc, lm, o));
     }
-    if (!r.dry())
-        OCRVI_TRY(k_db_tail(dt, d1.p, h->dc2_w, h->dc2_b, h->cfg.k, binary, thresh, tbin, blog, tlog, N, d1.h, d1.w, r.stream));
+    if (!r.dry()) OCRVI_TRY(k_db_maps(bl, tl, h->cfg.k, binary, thresh, tbin, map_elems, r.stream));
     return OCRVI_OK;
 }
 

@@ -177,7 +177,7 @@ ProfScope::~ProfScope() {
 
 static const char* amode_name(int amode, const ConvParams& p) {
     switch (amode) {
-        case AM_CONV1: return p.store_mode == ST_SHUFFLE2 ? "deconv2x2" : "conv1x1";
+        case AM_CONV1: return p.store_mode == ST_SHUFFLE2 ? "deconv2x2" : (p.store_mode == ST_DB_TAIL ? "deconv2x2_dbtail" : "conv1x1");
         case AM_CONV3: return p.store_mode == ST_DCN_OFFS ? "dcn_offset_conv3x3" : (p.groups > 1 ? "gconv3x3" : "conv3x3");
         case AM_ROWS: return "stem_conv";
         case AM_DCN: return "dcn3x3";

@@ -26,13 +26,18 @@ int k_frm_vertical(int dtype, const void* kv, const float* vq, void* out, int B,
 
 // Adaptive scale fusion (neck.py:57-79) fused: bilinear(align_corners=True) taps of p3..p5 at p2 resolution, 1x1 conv over the
 // virtual 1024-ch concat -> 4 scores -> softmax -> blend.  p_i: T NHWC [N,H>>i,W>>i,256]; w f32 [4][1024]; b f32 [4].
-int k_asf(int dtype, const void* p2, const void* p3, const void* p4, const void* p5, const float* w, const float* b, void* out, int N,
-          int H, int W, hipStream_t s);
+int k_asf(int dtype, const void* p2, const void* p3, const void* p4, const void* p5, const float* w, const float* b, float* scratch, void* out,
+          int N, int H, int W, hipStream_t s);
+size_t asf_scratch_bytes(int N, int H, int W);  // fp32 scratch for the coarse-level score maps
 // DB head tail (head.py:16,28-48): y T NHWC [N,H2,W2,128] (ch 0..63 binarise branch, 64..127 threshold branch, after deconv1+BN+ReLU)
 // -> ConvTranspose2d(64,1,2,2) per branch, sigmoid, step function.  w2 f32 [2][64][4], b2 f32 [2].  Outputs f32 [N,1,2*H2,2*W2]; any but
 // `binary` may be null.
 int k_db_tail(int dtype, const void* y, const float* w2, const float* b2, float k, float* binary, float* thresh, float* thresh_binary,
               float* bin_logits, float* thresh_logits, int N, int H2, int W2, hipStream_t s);
+
+// DB maps from the two logit maps (head.py:28-40); thresh / thresh_binary may be null.  n = elements per map (multiple of 4).
+int k_db_maps(const float* bin_logits, const float* thresh_logits, float k, float* binary, float* thresh, float* thresh_binary, size_t n,
+              hipStream_t s);
 
 // logits f32 [B*T][C] (row = b*T + t) -> log_softmax into log_probs [T][B][C] (nullable) and argmax [B][T] (nullable; first max wins).
 int k_ctc_logsoftmax_argmax(const float* logits, int ld, float* log_probs, int32_t* argmax_ids, int B, int T, int C, hipStream_t s);

@@ -260,79 +260,160 @@ int k_frm_vertical(int dtype, const void* kv, const float* vq, void* out, int B,
     return OCRVI_OK;
 }
 
-// ------------------------------------------------------------------ ASF (adaptive scale fusion), one wave per pixel, 4 ch per lane
+// ------------------------------------------------------------------ ASF (adaptive scale fusion, neck.py:57-79)
+// score = conv1x1(concat_l up(p_l)) = sum_l up(W_l . p_l): bilinear upsampling is linear and acts per channel, so it commutes
+// with the 1x1 attention conv.  (1) asf_scores_kernel: 4-channel fp32 score maps s_l = W_l . p_l for the three coarse levels at
+// their NATIVE resolution (1/4 + 1/16 + 1/64 of the pixels).  (2) asf_blend_kernel at p2 resolution: 16 lanes share a pixel
+// (16 channels = two 16-byte chunks per lane, 4 pixels per wave): own-level score by a 16-lane butterfly, coarse scores by
+// bilinear taps of the tiny maps, softmax over 4, then out = a0*p2 + sum_{l,tap} (a_l*w_tap) * p_l[tap].
 template <typename T>
-__global__ __launch_bounds__(256) void asf_kernel(const T* __restrict__ p2, const T* __restrict__ p3, const T* __restrict__ p4,
-                                                  const T* __restrict__ p5, const float* __restrict__ w, const float* __restrict__ bias,
-                                                  T* __restrict__ out, int N, int H, int W) {
+__global__ __launch_bounds__(256) void asf_scores_kernel(const T* __restrict__ p, const float* __restrict__ w, float* __restrict__ sc, int level,
+                                                         size_t npix) {
     const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
-    // attention weights for this lane's 4 channels: wreg[score i][level l][e]
-    float wreg[4][4][4];
+    float wr[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float4 t = *(const float4*)(w + i * 1024 + level * 256 + lane * 4);
+        wr[i][0] = t.x; wr[i][1] = t.y; wr[i][2] = t.z; wr[i][3] = t.w;
+    }
+    const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (size_t)gridDim.x * 4;
+    for (size_t pix = wave; pix < npix; pix += nwaves) {
+        float f[4];
+        load4<T>(p + pix * 256 + lane * 4, f);
+        float a[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = wave_sum(f[0] * wr[i][0] + f[1] * wr[i][1] + f[2] * wr[i][2] + f[3] * wr[i][3]);
+        if (lane == 0) *(float4*)(sc + pix * 4) = make_float4(a[0], a[1], a[2], a[3]);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void asf_blend_kernel(const T* __restrict__ p2, const T* __restrict__ p3, const T* __restrict__ p4,
+                                                        const T* __restrict__ p5, const float* __restrict__ s3, const float* __restrict__ s4,
+                                                        const float* __restrict__ s5, const float* __restrict__ w, const float* __restrict__ bias,
+                                                        T* __restrict__ out, int N, int H, int W) {
+    constexpr int EPC = TypeInfo<T>::EPC;   // channels per lane = one 16-byte chunk
+    constexpr int LPP = 256 / EPC;          // lanes per pixel (32 for bf16/fp16, 64 for fp32)
+    constexpr int PPW = 64 / LPP;           // pixels per wave pass
+    const int lane = threadIdx.x & 63, j = lane % LPP, sub = lane / LPP;
+    float w0[4][EPC];                       // level-0 attention weights of this lane's channels
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int l = 0; l < 4; ++l) {
-            const float4 t = *(const float4*)(w + i * 1024 + l * 256 + lane * 4);
-            wreg[i][l][0] = t.x; wreg[i][l][1] = t.y; wreg[i][l][2] = t.z; wreg[i][l][3] = t.w;
+        for (int e = 0; e < EPC; e += 4) {
+            const float4 t = *(const float4*)(w + i * 1024 + j * EPC + e);
+            w0[i][e] = t.x; w0[i][e + 1] = t.y; w0[i][e + 2] = t.z; w0[i][e + 3] = t.w;
         }
-    const T* lev[4] = {p2, p3, p4, p5};
-    const size_t total = (size_t)N * H * W;
-    for (size_t pix = wave; pix < total; pix += nwaves) {
-        const int x = (int)(pix % W);
-        const size_t t = pix / W;
-        const int y = (int)(t % H), n = (int)(t / H);
-        float f[4][4];
-        load4<T>(p2 + pix * 256 + lane * 4, f[0]);
+    const float4 bv = *(const float4*)bias;
+    const T* lev[3] = {p3, p4, p5};
+    const float* slev[3] = {s3, s4, s5};
+    // A workgroup sweeps compact 8x8 pixel tiles (one tile row of 8 pixels per pass: 4 waves x PPW pixels x 8/(4*PPW) passes) so the
+    // coarse-level taps (a 5x5 / 3x3 / 2x2 neighbourhood per tile) are re-used from L1 instead of being fetched from L2 per pixel.
+    const int tiles_x = W >> 3, tiles_y = H >> 3;
+    const int ntile = N * tiles_y * tiles_x;
+    const int wv = threadIdx.x >> 6;
+    constexpr int XPP = 4 * PPW;       // pixels of a tile row handled per pass
+    float shl[3], swl[3];  // align_corners=True scales (in-1)/(out-1) per coarse level
 #pragma unroll
-        for (int l = 1; l < 4; ++l) {
-            const int Hl = H >> l, Wl = W >> l;
-            // F.interpolate(bilinear, align_corners=True): src = dst * (in-1)/(out-1)  (neck.py:65)
-            const float sh = H > 1 ? (float)(Hl - 1) / (float)(H - 1) : 0.f, sw = W > 1 ? (float)(Wl - 1) / (float)(W - 1) : 0.f;
-            const float fy = sh * (float)y, fx = sw * (float)x;
-            const int y0 = (int)fy, x0 = (int)fx;
-            const int y1 = y0 + (y0 < Hl - 1 ? 1 : 0), x1 = x0 + (x0 < Wl - 1 ? 1 : 0);
-            const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
-            const T* base = lev[l] + (size_t)n * Hl * Wl * 256 + lane * 4;
-            float a[4], b[4], c[4], d[4];
-            load4<T>(base + ((size_t)y0 * Wl + x0) * 256, a);
-            load4<T>(base + ((size_t)y0 * Wl + x1) * 256, b);
-            load4<T>(base + ((size_t)y1 * Wl + x0) * 256, c);
-            load4<T>(base + ((size_t)y1 * Wl + x1) * 256, d);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) f[l][e] = hy * (hx * a[e] + lx * b[e]) + ly * (hx * c[e] + lx * d[e]);
-        }
+    for (int l = 0; l < 3; ++l) {
+        shl[l] = H > 1 ? (float)((H >> (l + 1)) - 1) / (float)(H - 1) : 0.f;
+        swl[l] = W > 1 ? (float)((W >> (l + 1)) - 1) / (float)(W - 1) : 0.f;
+    }
+    for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const int tx = tile % tiles_x, tt = tile / tiles_x, ty = tt % tiles_y, n = tt / tiles_y;
+    for (int it = 0; it < 8 * (8 / XPP); ++it) {
+        const int y = ty * 8 + it / (8 / XPP);
+        const int x = tx * 8 + (it % (8 / XPP)) * XPP + wv * PPW + sub;
+        const size_t pix = ((size_t)n * H + y) * W + x;
+        const bool ok = true;
+        const size_t pp = pix;
+        float f0[EPC];
+        Chunk<T>::unpack(*(const uint4*)(p2 + pp * 256 + j * EPC), f0);
         float sc[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float a = 0.f;
 #pragma unroll
-            for (int l = 0; l < 4; ++l)
+            for (int e = 0; e < EPC; ++e) a = fmaf(w0[i][e], f0[e], a);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) a = fmaf(wreg[i][l][e], f[l][e], a);
-            sc[i] = wave_sum(a) + bias[i];
+            for (int o = 1; o < LPP; o <<= 1) a += __shfl_xor(a, o);
+            sc[i] = a;
+        }
+        sc[0] += bv.x; sc[1] += bv.y; sc[2] += bv.z; sc[3] += bv.w;
+        // coarse levels: tap geometry (F.interpolate bilinear, align_corners=True: src = dst * (in-1)/(out-1), neck.py:65)
+        int toff[3][4];
+        float tw[3][4];
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+            const int Hl = H >> (l + 1), Wl = W >> (l + 1);
+            const float fy = shl[l] * (float)y, fx = swl[l] * (float)x;
+            const int y0 = (int)fy, x0 = (int)fx;
+            const int y1 = y0 + (y0 < Hl - 1 ? 1 : 0), x1 = x0 + (x0 < Wl - 1 ? 1 : 0);
+            const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+            const int b0 = n * Hl * Wl;
+            toff[l][0] = b0 + y0 * Wl + x0; toff[l][1] = b0 + y0 * Wl + x1;
+            toff[l][2] = b0 + y1 * Wl + x0; toff[l][3] = b0 + y1 * Wl + x1;
+            tw[l][0] = hy * hx; tw[l][1] = hy * lx; tw[l][2] = ly * hx; tw[l][3] = ly * lx;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 sv = *(const float4*)(slev[l] + (size_t)toff[l][q] * 4);
+                sc[0] = fmaf(tw[l][q], sv.x, sc[0]); sc[1] = fmaf(tw[l][q], sv.y, sc[1]);
+                sc[2] = fmaf(tw[l][q], sv.z, sc[2]); sc[3] = fmaf(tw[l][q], sv.w, sc[3]);
+            }
         }
         const float mx = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
         float den = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { sc[i] = __expf(sc[i] - mx); den += sc[i]; }
         const float inv = 1.f / den;
-        float o[4];
+        float o[EPC];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (f[0][e] * sc[0] + f[1][e] * sc[1] + f[2][e] * sc[2] + f[3][e] * sc[3]) * inv;
-        store4<T>(out + pix * 256 + lane * 4, o);
+        for (int e = 0; e < EPC; ++e) o[e] = f0[e] * (sc[0] * inv);
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+            const float al = sc[l + 1] * inv;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float cf = al * tw[l][q];
+                float f[EPC];
+                Chunk<T>::unpack(*(const uint4*)(lev[l] + (size_t)toff[l][q] * 256 + j * EPC), f);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) o[e] = fmaf(cf, f[e], o[e]);
+            }
+        }
+        if (ok) *(uint4*)(out + pix * 256 + j * EPC) = Chunk<T>::pack(o);
+    }
     }
 }
-int k_asf(int dtype, const void* p2, const void* p3, const void* p4, const void* p5, const float* w, const float* b, void* out, int N,
-          int H, int W, hipStream_t s) {
-    OCRVI_CHECK(p2 && p3 && p4 && p5 && w && b && out && H % 8 == 0 && W % 8 == 0, OCRVI_EINVAL, "asf: bad shape %dx%d", H, W);
-    ProfScope ps_("asf_fused", 0.0, (double)N*H*W*256*dtype_size(dtype)*(2.0+1.0/4+1.0/16+1.0/64), s);
+
+template <typename T>
+static void asf_launch(const void* p2, const void* p3, const void* p4, const void* p5, const float* w, const float* b, float* s3, float* s4,
+                       float* s5, void* out, int N, int H, int W, hipStream_t s) {
+    const void* lv[3] = {p3, p4, p5};
+    float* sv[3] = {s3, s4, s5};
+    for (int l = 0; l < 3; ++l) {
+        const size_t np = (size_t)N * (H >> (l + 1)) * (W >> (l + 1));
+        const int grid = (int)std::min<size_t>((np + 3) / 4, 2048);
+        hipLaunchKernelGGL(asf_scores_kernel<T>, dim3(grid), dim3(256), 0, s, (const T*)lv[l], w, sv[l], l + 1, np);
+    }
     const size_t total = (size_t)N * H * W;
-    const int grid = (int)std::min<size_t>((total + 3) / 4, 256 * 8);
-    DISPATCH_DT(dtype, hipLaunchKernelGGL(asf_kernel<T>, dim3(grid), dim3(256), 0, s, (const T*)p2, (const T*)p3, (const T*)p4, (const T*)p5, w, b, (T*)out, N, H, W));
+    const int grid = (int)std::min<size_t>(total / 64, 256 * 8);
+    hipLaunchKernelGGL(asf_blend_kernel<T>, dim3(grid), dim3(256), 0, s, (const T*)p2, (const T*)p3, (const T*)p4, (const T*)p5, s3, s4, s5, w, b,
+                       (T*)out, N, H, W);
+}
+
+int k_asf(int dtype, const void* p2, const void* p3, const void* p4, const void* p5, const float* w, const float* b, float* scratch, void* out,
+          int N, int H, int W, hipStream_t s) {
+    OCRVI_CHECK(p2 && p3 && p4 && p5 && w && b && out && scratch && H % 8 == 0 && W % 8 == 0, OCRVI_EINVAL, "asf: bad shape %dx%d", H, W);
+    const size_t n3 = (size_t)N * (H / 2) * (W / 2), n4 = (size_t)N * (H / 4) * (W / 4);
+    float *s3 = scratch, *s4 = s3 + n3 * 4, *s5 = s4 + n4 * 4;
+    ProfScope ps_("asf_fused", 0.0, (double)N * H * W * 256 * dtype_size(dtype) * (2.0 + 1.0 / 4 + 1.0 / 16 + 1.0 / 64), s);
+    DISPATCH_DT(dtype, asf_launch<T>(p2, p3, p4, p5, w, b, s3, s4, s5, out, N, H, W, s));
     OCRVI_HIP(hipGetLastError());
     return OCRVI_OK;
 }
+// bytes of fp32 scratch k_asf needs for the coarse score maps
+size_t asf_scratch_bytes(int N, int H, int W) { return ((size_t)N * (H / 2) * (W / 2) + (size_t)N * (H / 4) * (W / 4) + (size_t)N * (H / 8) * (W / 8)) * 16; }
 
 // ------------------------------------------------------------------ DB head tail: deconv2 (64->1, 2x2 s2) x2 branches + sigmoid + step
 // 128/EPC lanes share one pixel's 128-channel row (one 16-byte chunk per lane -> the wave reads whole contiguous rows):
@@ -407,6 +488,33 @@ int k_db_tail(int dtype, const void* y, const float* w2, const float* b2, float 
     const size_t total = (size_t)N * H2 * W2;
     const int grid = (int)std::min<size_t>((total + 15) / 16, 256 * 8);
     DISPATCH_DT(dtype, hipLaunchKernelGGL(db_tail_kernel<T>, dim3(grid), dim3(256), 0, s, (const T*)y, w2, b2, k, binary, thresh, thresh_binary, bin_logits, thresh_logits, N, H2, W2));
+    OCRVI_HIP(hipGetLastError());
+    return OCRVI_OK;
+}
+
+// logits -> binary = sigmoid(bin), thresh = sigmoid(thr), thresh_binary = 1/(1+exp(-k(binary-thresh)))  (head.py:28-40)
+__global__ void db_maps_kernel(const float* __restrict__ bl, const float* __restrict__ tl, float k, float* __restrict__ binary,
+                               float* __restrict__ thresh, float* __restrict__ tbin, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 b = ((const float4*)bl)[i], t = ((const float4*)tl)[i];
+        float4 pb, pt, st;
+        pb.x = 1.f / (1.f + expf(-b.x)); pb.y = 1.f / (1.f + expf(-b.y)); pb.z = 1.f / (1.f + expf(-b.z)); pb.w = 1.f / (1.f + expf(-b.w));
+        pt.x = 1.f / (1.f + expf(-t.x)); pt.y = 1.f / (1.f + expf(-t.y)); pt.z = 1.f / (1.f + expf(-t.z)); pt.w = 1.f / (1.f + expf(-t.w));
+        ((float4*)binary)[i] = pb;
+        if (thresh) ((float4*)thresh)[i] = pt;
+        if (tbin) {
+            st.x = 1.f / (1.f + expf(-k * (pb.x - pt.x))); st.y = 1.f / (1.f + expf(-k * (pb.y - pt.y)));
+            st.z = 1.f / (1.f + expf(-k * (pb.z - pt.z))); st.w = 1.f / (1.f + expf(-k * (pb.w - pt.w)));
+            ((float4*)tbin)[i] = st;
+        }
+    }
+}
+int k_db_maps(const float* bin_logits, const float* thresh_logits, float k, float* binary, float* thresh, float* thresh_binary, size_t n,
+              hipStream_t s) {
+    OCRVI_CHECK(bin_logits && thresh_logits && binary && n % 4 == 0, OCRVI_EINVAL, "db maps: bad argument");
+    ProfScope ps_("db_maps", 0.0, (double)n * 4 * (3 + (thresh ? 1 : 0) + (thresh_binary ? 1 : 0)), s);
+    const int grid = (int)std::min<size_t>((n / 4 + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(db_maps_kernel, dim3(grid), dim3(256), 0, s, bin_logits, thresh_logits, k, binary, thresh, thresh_binary, n / 4);
     OCRVI_HIP(hipGetLastError());
     return OCRVI_OK;
 }

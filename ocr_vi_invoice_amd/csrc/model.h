@@ -64,7 +64,8 @@ struct ConvOpts {
     int res_mode = RES_NONE;
     int res_post = 0;
     int store_mode = ST_NHWC;
-    const float* offs = nullptr;  // AM_DCN
+    const float* offs = nullptr;  // AM_DCN offsets, or ST_DB_TAIL second-deconv weights [2][64][4] + biases [2]
+    void* out2 = nullptr;         // ST_DB_TAIL: threshold-branch logit map
     int out_coff = 0;
     int cin_off = 0;
     int Hp = 0, Wp = 0;  // AM_ROWS padded input dims

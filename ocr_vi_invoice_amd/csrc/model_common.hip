@@ -43,6 +43,8 @@ int conv(Runner& r, const ConvLayer& L, const Tensor& x, const Tensor& y, const 
     p.store_mode = o.store_mode;
     if (o.store_mode == ST_SHUFFLE2) {
         p.OH = y.h / 2; p.OW = y.w / 2; p.shuffle_co = L.shuffle_co;
+    } else if (o.store_mode == ST_DB_TAIL) {  // y is the fp32 logit map [n, 4*OH, 4*OW, 1]
+        p.OH = y.h / 4; p.OW = y.w / 4; p.shuffle_co = L.shuffle_co; p.out2 = o.out2;
     } else {
         p.OH = y.h; p.OW = y.w;
     }
