@@ -269,9 +269,16 @@ def main():
                 ach, peak, u, bound = d["flops"] / secs / 1e12, PEAK_TFLOPS[args.dtype], "TFLOP/s", "mfma"
             else:
                 ach, peak, u, bound = d["bytes"] / secs / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
+            traffic = None   # HBM-side bytes per launch from the PMC passes committed under profiles/ (separate rocprofv3 runs)
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"].get(name)
+                traffic = pmc["traffic_bytes_per_launch"] if pmc else None
+            except (OSError, ValueError, KeyError):
+                pass
             res["roofline"] = {"kernel": name, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": u, "frac": round(ach / peak, 4),
-                               "traffic": None, "launches": d["launches"], "avg_ms": round(d["ms"] / d["launches"], 4),
-                               "algorithmic_per_launch": round((d["flops"] if d["flops"] > 0 else d["bytes"]) / d["launches"], 1),
+                               "traffic": traffic, "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"], 1),
+                               "launches": d["launches"], "avg_ms": round(d["ms"] / d["launches"], 4),
+                               "algorithmic_flops_per_launch": round(d["flops"] / d["launches"], 1),
                                "timed_by": "HIP events on the launch stream around every launch, " +
                                            ("one extra eager step after the graph-replayed timed region" if graph_mode else "over the timed region")}
             tot = sum(v["ms"] for v in prof.values())
