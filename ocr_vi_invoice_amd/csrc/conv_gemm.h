@@ -33,6 +33,8 @@ struct ConvParams {
     const float* bias = nullptr;  // f32 [groups*N_g] or null
     void* out = nullptr;          // T or f32
     void* out2 = nullptr;         // ST_DB_TAIL: logit map of group 1 (threshold branch); `out` is group 0's
+    const void* zero_page = nullptr;  // gemm_ring: >= 128 B of zeros (source of A rows past M)
+    void* dump_page = nullptr;        // gemm_ring: >= 1 KiB sink for the stores of out-of-range lanes
     const void* res = nullptr;    // T or f32, or null
     const float* offs = nullptr;  // AM_DCN: f32 [M][32] = 18 offsets (dy,dx per tap), 9 sigmoided masks, 5 pad
     int n_img = 1, H = 1, W = 1, Cin = 0;

@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include "conv_gemm.h"
+#include "gemm_ring.h"
 
 namespace ocrvi {
 
@@ -34,6 +35,37 @@ static int launch_tile(const ConvParams& p, hipStream_t stream) {
     hipLaunchKernelGGL(kern, dim3(grid_x, p.groups), dim3(256), smem, stream, p);
     OCRVI_HIP(hipGetLastError());
     return OCRVI_OK;
+}
+
+template <typename T, int BM>
+static int launch_ring_bm(const ConvParams& p, hipStream_t stream) {
+    constexpr int smem = 3 * (BM + 128) * 128;
+    auto kern = gemm_ring_kernel<T, BM>;
+    static bool attr_done = false;
+    static int n_cu = 0;
+    if (!attr_done) {
+        OCRVI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        int dev = 0;
+        hipDeviceProp_t prop;
+        OCRVI_HIP(hipGetDevice(&dev));
+        OCRVI_HIP(hipGetDeviceProperties(&prop, dev));
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        attr_done = true;
+    }
+    const int total = cdiv(p.M, BM) * (p.Np / 128);
+    const int grid = cdiv(total, cdiv(total, n_cu));  // one persistent workgroup per CU, equal tile counts
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, stream, p);
+    OCRVI_HIP(hipGetLastError());
+    return OCRVI_OK;
+}
+
+template <typename T>
+int launch_gemm_ring(const ConvParams& p_in, hipStream_t stream) {
+    ConvParams p = p_in;
+    OCRVI_TRY(ring_pages(&p.zero_page, &p.dump_page));
+    // 256-row tiles when that still gives every CU work; 128-row tiles for short M
+    if (cdiv(p.M, 256) * (p.Np / 128) >= 192) return launch_ring_bm<T, 256>(p, stream);
+    return launch_ring_bm<T, 128>(p, stream);
 }
 
 template <typename T, int AMODE>
@@ -105,6 +137,7 @@ int launch_conv(const ConvParams& p_in, int amode, hipStream_t stream) {
     OCRVI_CHECK(p.Kp >= ks * ks * p.Cin_g, OCRVI_EINVAL, "conv: Kp=%d < %d", p.Kp, ks * ks * p.Cin_g);
     OCRVI_CHECK((p.OH - 1) * p.SH - p.PH + ks - 1 < p.H + ks && (p.OW - 1) * p.SW - p.PW + ks - 1 < p.W + ks, OCRVI_EINVAL,
                 "conv: output %dx%d inconsistent with input %dx%d", p.OH, p.OW, p.H, p.W);
+    if (gemm_ring_eligible(p, amode, TypeInfo<T>::dtype)) return launch_gemm_ring<T>(p, stream);
     switch (amode) {
         case AM_CONV1: return launch_mode<T, AM_CONV1>(p, stream);
         case AM_CONV3: return launch_mode<T, AM_CONV3>(p, stream);

@@ -7,6 +7,7 @@
 #include <mutex>
 
 #include "conv_gemm.h"
+#include "gemm_ring.h"
 
 namespace ocrvi {
 
@@ -185,6 +186,37 @@ static const char* amode_name(int amode, const ConvParams& p) {
     return "conv";
 }
 
+bool gemm_ring_eligible(const ConvParams& p, int amode, int dtype) {
+    static const bool on = !(getenv("OCRVI_GEMM_RING") && atoi(getenv("OCRVI_GEMM_RING")) == 0);
+    if (!on || amode != AM_CONV1 || !p.identity_pix || p.groups != 1 || p.store_mode != ST_NHWC) return false;
+    if (p.res_mode != RES_NONE && p.res_mode != RES_SAME) return false;
+    const int esz = (int)dtype_size(dtype), bke = conv_bke(dtype);
+    if (p.Cin_g % bke != 0 || p.Kp != p.Cin_g || p.N_g < 128 || p.N_g % 4 != 0 || p.Np % 128 != 0) return false;
+    if (((size_t)p.cin_off * esz) % 16 != 0 || ((size_t)p.Cin * esz) % 16 != 0 || ((uintptr_t)p.x & 15) != 0) return false;
+    if (p.ldo % 4 != 0 || p.out_coff % 4 != 0 || ((uintptr_t)p.out & 15) != 0) return false;
+    if (p.res_mode == RES_SAME && (p.ldr % 4 != 0 || ((uintptr_t)p.res & 15) != 0)) return false;
+    return true;
+}
+
+int ring_pages(const void** zero_page, void** dump_page) {
+    // one 8 KiB device allocation per process and device: [0, 4096) zeros, [4096, 8192) write sink.  Never freed.
+    static std::mutex mu;
+    static std::map<int, char*> pages;
+    std::lock_guard<std::mutex> lk(mu);
+    int dev = 0;
+    OCRVI_HIP(hipGetDevice(&dev));
+    auto it = pages.find(dev);
+    if (it == pages.end()) {
+        char* p = nullptr;
+        OCRVI_HIP(hipMalloc((void**)&p, 8192));
+        OCRVI_HIP(hipMemset(p, 0, 8192));
+        it = pages.emplace(dev, p).first;
+    }
+    *zero_page = it->second;
+    *dump_page = it->second + 4096;
+    return OCRVI_OK;
+}
+
 int launch_conv_dt(int dtype, const ConvParams& p, int amode, hipStream_t stream) {
     char tag[160];
     double flops = 0, bytes = 0;
@@ -197,12 +229,16 @@ int launch_conv_dt(int dtype, const ConvParams& p, int amode, hipStream_t stream
         bytes = (double)p.n_img * p.H * p.W * (amode == AM_ROWS ? 4 : p.Cin_g * p.groups) * esz + (double)p.N_g * p.groups * kvalid * esz +
                 (double)p.M * p.N_g * p.groups * (p.out_f32 ? 4.0 : esz) + (p.res ? (double)p.M * p.N_g * p.groups * (p.res_f32 ? 4.0 : esz) : 0.0) +
                 (p.offs ? (double)p.M * 27 * 4 : 0.0);
+        ConvParams q = p;   // identity_pix is set inside launch_conv; recompute it here for the tag only
+        q.identity_pix = (amode == AM_CONV1 && p.SH == 1 && p.SW == 1 && p.PH == 0 && p.PW == 0 && p.H == p.OH && p.W == p.OW &&
+                          p.store_mode == ST_NHWC && p.res_mode != RES_UP2) ? 1 : 0;
+        const bool ring = gemm_ring_eligible(q, amode, dtype);
         static const bool detail = getenv("OCRVI_PROF_DETAIL") != nullptr;
         if (detail)
-            snprintf(tag, sizeof(tag), "%s_%dx%d_%s M%d N%d K%d g%d s%d", amode_name(amode, p), amode == AM_DCN ? 64 : 128, (amode == AM_DCN && p.Np % 256 == 0) ? 256 : conv_bn_for(p.N_g), dtype_name(dtype), p.M,
+            snprintf(tag, sizeof(tag), "%s%s_%dx%d_%s M%d N%d K%d g%d s%d", ring ? "ring_" : "", amode_name(amode, p), amode == AM_DCN ? 64 : 128, (amode == AM_DCN && p.Np % 256 == 0) ? 256 : conv_bn_for(p.N_g), dtype_name(dtype), p.M,
                      p.N_g, (int)kvalid, p.groups, p.SH);
         else
-            snprintf(tag, sizeof(tag), "%s_%dx%d_%s", amode_name(amode, p), amode == AM_DCN ? 64 : 128, (amode == AM_DCN && p.Np % 256 == 0) ? 256 : conv_bn_for(p.N_g), dtype_name(dtype));
+            snprintf(tag, sizeof(tag), "%s%s_%dx%d_%s", ring ? "ring_" : "", amode_name(amode, p), amode == AM_DCN ? 64 : 128, (amode == AM_DCN && p.Np % 256 == 0) ? 256 : conv_bn_for(p.N_g), dtype_name(dtype));
     }
     ProfScope ps(tag, flops, bytes, stream);
     switch (dtype) {
