@@ -234,7 +234,9 @@ int launch_conv_dt(int dtype, const ConvParams& p, int amode, hipStream_t stream
                           p.store_mode == ST_NHWC && p.res_mode != RES_UP2) ? 1 : 0;
         const bool ring = gemm_ring_eligible(q, amode, dtype);
         static const bool detail = getenv("OCRVI_PROF_DETAIL") != nullptr;
-        if (detail)
+        if (ring && !detail)
+            snprintf(tag, sizeof(tag), "gemm_ring_%s", dtype_name(dtype));
+        else if (detail)
             snprintf(tag, sizeof(tag), "%s%s_%dx%d_%s M%d N%d K%d g%d s%d", ring ? "ring_" : "", amode_name(amode, p), amode == AM_DCN ? 64 : 128, (amode == AM_DCN && p.Np % 256 == 0) ? 256 : conv_bn_for(p.N_g), dtype_name(dtype), p.M,
                      p.N_g, (int)kvalid, p.groups, p.SH);
         else
