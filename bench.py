@@ -234,13 +234,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    # Rehearsal switch for a 1-GPU box: OCRVI_BENCH_REHEARSE=1 puts every rank on cuda:0 and uses gloo for the (CPU-side) collectives.
+    rehearse = os.environ.get("OCRVI_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
+    cdev = "cpu" if rehearse else dev           # device the collectives run on
     from ocr_vi_invoice_amd import _lib, synth, weights
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device(dev))  # RCCL over xGMI
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(dev))  # RCCL over xGMI
 
     # ---- weights: built on rank 0, broadcast once over RCCL (the only collective on the path)
     det_sd = weights.make_det_state_dict(seed=1234)
@@ -248,7 +256,7 @@ def main():
     bcast_ms = None
     if world > 1:
         from ocr_vi_invoice_amd.dist import broadcast_weights
-        bcast_ms = broadcast_weights([det_sd, rec_sd], dev, dist)
+        bcast_ms = broadcast_weights([det_sd, rec_sd], cdev, dist)
 
     # ---- synthetic inputs (this rank's shard)
     imgs, boxes = [], []
@@ -293,7 +301,7 @@ def main():
     dt = time.perf_counter() - t0
     if dist:
         from ocr_vi_invoice_amd.dist import max_over_ranks
-        dt = max_over_ranks(dt, dev, dist)
+        dt = max_over_ranks(dt, cdev, dist)
     prof, prof_steps = {}, args.steps
     if not args.no_prof:
         if graph_mode:

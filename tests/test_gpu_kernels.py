@@ -72,6 +72,33 @@ def test_conv_kernel(case, dt):
     assert _rel_err(out, ref) < TOL[dt], _rel_err(out, ref)
 
 
+RING_CASES = [
+    # stride-1 1x1 convs / Linears that take the persistent LDS-DMA ring GEMM (gemm_ring.h): N, Cin, H, W, Co, act
+    (3, 384, 37, 29, 232, 0),     # ragged M (3219 rows: tails of both the 256- and the 128-row tile), N tail 232 -> 256
+    (1, 128, 1, 300, 512, 2),     # short M (forces the 128-row tile), GELU
+    (5, 1536, 16, 16, 384, 0),    # K = 24 ring steps (bf16), 3 N tiles
+    (2, 64, 50, 41, 256, 1),      # single K step per tile: the ring crosses a tile boundary every step
+    (7, 256, 33, 31, 1024, 2),    # many N tiles per M tile
+]
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("case", RING_CASES)
+def test_ring_gemm_kernel(case, dt):
+    N, Cin, H, W, Co, act = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Co, Cin, 1, 1, generator=g) / np.sqrt(Cin)
+    b = torch.randn(Co, generator=g) * 0.1
+    ref = F.conv2d(x, w, b)
+    ref = F.relu(ref) if act == 1 else (F.gelu(ref) if act == 2 else ref)
+    out = run_conv(x, w, b, 1, 1, 1, 1, act, dt)
+    assert out.shape == ref.shape
+    assert _rel_err(out, ref) < TOL[dt], _rel_err(out, ref)
+    out2 = run_conv(x, w, b, 1, 1, 1, 1, act, dt)
+    assert torch.equal(out, out2)     # the ring has no data race: repeated launches are bit-identical
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("stride", [1, 2])
 @pytest.mark.parametrize("C_", [128, 256])
