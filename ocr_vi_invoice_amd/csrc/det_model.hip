@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <memory>
 
+#include "gemm_ring.h"
 #include "model.h"
 
 using namespace ocrvi;
@@ -99,6 +100,10 @@ extern "C" int ocrvi_det_create(int device, const void* blob_p, size_t blob_byte
         w2.insert(w2.end(), b2.begin(), b2.end());
         OCRVI_TRY(st.upload_f32(w2, &h->dc2_wb));
     }
+    {   // scratch pages of the ring GEMM: allocate now so no forward (possibly under graph capture) ever allocates
+        const void* z; void* d;
+        OCRVI_TRY(ring_pages(&z, &d));
+    }
     *out = h.release();
     return OCRVI_OK;
 }
@@ -113,7 +118,9 @@ static int check_det_shape(const ocrvi_det* h, int N, int H, int W) {
     OCRVI_CHECK(h, OCRVI_EINVAL, "det: null handle");
     OCRVI_CHECK(N > 0 && H >= 32 && W >= 32 && H % 32 == 0 && W % 32 == 0, OCRVI_EINVAL,
                 "det: input (N=%d,3,%d,%d) needs H and W to be multiples of 32", N, H, W);
-    OCRVI_CHECK((size_t)N * H * W <= ((size_t)1 << 26), OCRVI_EINVAL, "det: batch of %d %dx%d images too large for one call (chunk it)", N, H, W);
+    // the stem's GEMM has N*(H/2)*(W/2) rows and the conv kernels index rows with 23 bits (magic-number division)
+    OCRVI_CHECK((size_t)N * (H / 2) * (W / 2) < ((size_t)1 << 23), OCRVI_EINVAL,
+                "det: batch of %d %dx%d images too large for one call (at most %zu pixels per call: chunk it)", N, H, W, ((size_t)1 << 25) - 1);
     return OCRVI_OK;
 }
 

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <memory>
 
+#include "gemm_ring.h"
 #include "model.h"
 
 using namespace ocrvi;
@@ -107,6 +108,10 @@ extern "C" int ocrvi_rec_create(int device, const void* blob_p, size_t blob_byte
     OCRVI_TRY(load_mlp(st, blob, "frm.v_mlp", d, dt, &h->v_mlp));
     OCRVI_TRY(load_vec(st, blob, "frm.vq", d, &h->vq));
     OCRVI_TRY(load_lin(st, blob, "head", cfg->num_classes, d, dt, &h->head));
+    {   // scratch pages of the ring GEMM: allocate now so no forward (possibly under graph capture) ever allocates
+        const void* z; void* d;
+        OCRVI_TRY(ring_pages(&z, &d));
+    }
     *out = h.release();
     return OCRVI_OK;
 }
@@ -123,7 +128,7 @@ static int check_rec_shape(const ocrvi_rec* h, int B, int H, int W) {
                 "rec: input (B=%d,3,%d,%d) needs H %% 16 == 0 and W %% 4 == 0", B, H, W);
     OCRVI_CHECK((H / 4) * (W / 4) / 2 <= 512 && H / 16 <= 8, OCRVI_EINVAL,
                 "rec: %dx%d gives more than 512 tokens in the first global-attention stage (unsupported)", H, W);
-    OCRVI_CHECK((size_t)B * (H / 4) * (W / 4) < ((size_t)1 << 24), OCRVI_EINVAL, "rec: batch too large");
+    OCRVI_CHECK((size_t)B * (H / 2) * (W / 2) < ((size_t)1 << 23), OCRVI_EINVAL, "rec: batch of %d %dx%d crops too large for one call (chunk it)", B, H, W);
     return OCRVI_OK;
 }
 

@@ -1,0 +1,106 @@
+"""Host-side mirror of the reference pipeline's helpers (src/pipeline/pipeline2.py) on top of libocrvi.
+
+Same names and argument meaning as the reference for the pieces either side of the two models:
+``load_detection_model`` (:43), ``load_recognition_model`` (:72), ``preprocess_for_recognition`` (:92), ``recognize_text`` (:131),
+``recognize_text_batch`` (:144), ``crop_image`` (src/det/test.py:123) plus ``normalize_for_det`` (the inline code at :312-314).
+Image resizing and crop pre-processing run on the GPU (ocrvi_crop_resize_normalize / ocrvi_normalize_u8).
+
+Not provided yet: ``DBPostProcessor`` (src/det/test.py:46-106; cv2.findContours / approxPolyDP / pyclipper) -- the next row in
+DESIGN.md section 7.  A caller that has cv2 keeps using the reference's own post-processor on ``det(x)['binary']``.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .det import DBNetPP
+from .rec import SVTRv2
+
+
+def load_detection_model(model_path: str, device: str = "cuda:0", dtype: str = "bf16") -> DBNetPP:
+    """pipeline2.py:43-67.  The checkpoint is read with ``weights_only=True`` (nothing in the file is executed)."""
+    ckpt = torch.load(model_path, map_location="cpu", weights_only=True)
+    return DBNetPP(pretrained=False, state_dict=ckpt, device=device, dtype=dtype)
+
+
+def load_recognition_model(model_path: str, device: str = "cuda:0", variant: str = "base", dtype: str = "bf16") -> SVTRv2:
+    """pipeline2.py:72-89."""
+    ckpt = torch.load(model_path, map_location="cpu", weights_only=True)
+    return SVTRv2(variant=variant, in_channels=3, state_dict=ckpt, device=device, dtype=dtype)
+
+
+def _dev_index(device) -> int:
+    d = torch.device(device)
+    return d.index if d.index is not None else torch.cuda.current_device()
+
+
+def normalize_for_det(images_u8: torch.Tensor) -> torch.Tensor:
+    """uint8 HWC [N,H,W,3] on the device -> float32 NCHW, exactly the arithmetic of pipeline2.py:312-314."""
+    if images_u8.dim() == 3:
+        images_u8 = images_u8[None]
+    images_u8 = images_u8.contiguous()
+    N, H, W, C = images_u8.shape
+    assert C == 3 and images_u8.dtype == torch.uint8 and images_u8.is_cuda
+    out = torch.empty((N, 3, H, W), dtype=torch.float32, device=images_u8.device)
+    stream = torch.cuda.current_stream(images_u8.device).cuda_stream
+    _lib.check(_lib.load().ocrvi_normalize_u8(_dev_index(images_u8.device), images_u8.data_ptr(), N, H, W, out.data_ptr(), stream))
+    return out
+
+
+def crop_rect(img_hw: Tuple[int, int], box) -> Tuple[int, int, int, int]:
+    """The rectangle crop_image (src/det/test.py:123-130) slices: cv2.boundingRect of the integer box, clamped to the image."""
+    h, w = img_hw
+    pts = np.asarray(box).reshape(-1, 2)
+    x0, y0 = int(pts[:, 0].min()), int(pts[:, 1].min())
+    bw, bh = int(pts[:, 0].max()) - x0 + 1, int(pts[:, 1].max()) - y0 + 1     # boundingRect of integer points is inclusive
+    x, y = max(0, x0), max(0, y0)
+    return x, y, max(min(bw, w - x), 0), max(min(bh, h - y), 0)
+
+
+def crop_image(img: np.ndarray, box) -> np.ndarray:
+    x, y, bw, bh = crop_rect(img.shape[:2], box)
+    return img[y:y + bh, x:x + bw]
+
+
+def preprocess_crops(images_u8: torch.Tensor, rects: Sequence[Sequence[int]], img_size: Tuple[int, int] = (32, 256)) -> torch.Tensor:
+    """Batched crop + preprocess_for_recognition (pipeline2.py:92-128) on the device.
+    images_u8 [N,H,W,3] uint8 on the device; rects = (image index, x, y, w, h) -> float32 [B,3,h,w]."""
+    images_u8 = images_u8.contiguous()
+    N, H, W, _ = images_u8.shape
+    r = torch.as_tensor(np.asarray(rects, dtype=np.int32).reshape(-1, 5), device=images_u8.device)
+    out = torch.empty((r.shape[0], 3, img_size[0], img_size[1]), dtype=torch.float32, device=images_u8.device)
+    stream = torch.cuda.current_stream(images_u8.device).cuda_stream
+    _lib.check(_lib.load().ocrvi_crop_resize_normalize(_dev_index(images_u8.device), images_u8.data_ptr(), N, H, W, r.data_ptr(), r.shape[0],
+                                                       img_size[0], img_size[1], out.data_ptr(), stream))
+    return out
+
+
+def preprocess_for_recognition(crop: np.ndarray, img_size: Tuple[int, int] = (32, 256), device: str = "cuda:0") -> torch.Tensor:
+    """pipeline2.py:92-128 for one crop (HxWx3 uint8, or HxW grey which is replicated as cv2.COLOR_GRAY2RGB does) -> [3,h,w]."""
+    if crop.ndim == 2:
+        crop = np.repeat(crop[:, :, None], 3, axis=2)
+    crop = np.ascontiguousarray(crop[:, :, :3])
+    if crop.size == 0:
+        return torch.zeros((3,) + tuple(img_size), device=device)
+    img = torch.from_numpy(crop).to(device)[None]
+    return preprocess_crops(img, [(0, 0, 0, crop.shape[1], crop.shape[0])], img_size)[0]
+
+
+def recognize_text(model: SVTRv2, crop: np.ndarray, device: str = "cuda:0", img_size: Tuple[int, int] = (32, 256)) -> str:
+    """pipeline2.py:131-141."""
+    out = recognize_text_batch(model, [crop], device, img_size, 1)
+    return out[0] if out else ""
+
+
+def recognize_text_batch(model: SVTRv2, crops: List[np.ndarray], device: str = "cuda:0", img_size: Tuple[int, int] = (32, 256),
+                         batch_size: int = 32) -> List[str]:
+    """pipeline2.py:144-168: batches of ``batch_size`` crops -> forward -> greedy CTC strings.  Empty crops become the all-zero tensor
+    of :154-156."""
+    texts: List[str] = []
+    for i in range(0, len(crops), batch_size):
+        ts = [preprocess_for_recognition(c, img_size, device) for c in crops[i:i + batch_size]]
+        texts.extend(model.decode_greedy(torch.stack(ts)))
+    return texts

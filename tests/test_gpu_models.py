@@ -128,6 +128,16 @@ def test_dbnet_lowp_error_budget(dt, tol):
     assert err < tol
 
 
+def test_batch_limits_are_reported_not_crashed():
+    from ocr_vi_invoice_amd import DBNetPP, SVTRv2
+    m = DBNetPP(pretrained=False, dtype="bf16")
+    with pytest.raises(ValueError, match="too large"):
+        m._workspace(32, 960, 1280)                     # 32 pages exceed the per-call row limit; the error says to chunk
+    r = SVTRv2("tiny", dtype="bf16")
+    with pytest.raises(ValueError, match="too large"):
+        r._workspace(40000, 32, 128)
+
+
 def test_dbnet_bad_shapes_raise():
     from ocr_vi_invoice_amd import DBNetPP
     with pytest.raises(NotImplementedError):
