@@ -145,3 +145,38 @@ def test_dbnet_bad_shapes_raise():
     m = DBNetPP(pretrained=False, dtype="bf16")
     with pytest.raises(ValueError):
         m(torch.zeros(1, 3, 60, 96, device="cuda"))
+
+
+@pytest.mark.parametrize("shape", [(1, 16, 8), (3, 32, 100), (2, 48, 36), (1, 64, 320), (5, 16, 512)])
+def test_svtrv2_small_and_ragged_shapes_match_oracle(shape):
+    """Edge shapes: minimum height 16 (one token row after both merges), widths that give odd / tiny token counts (T = 2, 25, 9),
+    the widest sequence the attention kernel holds (64x320 -> 640 / 320 tokens... first global stage 8*80 = 640 > 512 is rejected)."""
+    from ocr_vi_invoice_amd import SVTRv2, weights
+    from oracle import svtrv2_cpu
+    B, H, W = shape
+    sd = weights.make_rec_state_dict("tiny", seed=5)
+    m = SVTRv2("tiny", state_dict=sd, dtype="f32")
+    x = torch.randn(B, 3, H, W, generator=torch.Generator().manual_seed(H * W))
+    if (H // 8) * (W // 4) > 512:
+        with pytest.raises(ValueError, match="512 tokens"):
+            m(x.cuda())
+        return
+    ref = svtrv2_cpu.forward(sd, x, "tiny")
+    lp = m(x.cuda())
+    assert lp.shape == (W // 4, B, 232)
+    np.testing.assert_allclose(lp.cpu().numpy(), ref.numpy(), atol=1e-3)
+    from ocr_vi_invoice_amd.vocab import Tokenizer
+    assert m.decode_probs(lp) == Tokenizer().decode(svtrv2_cpu.greedy_ids(ref))
+
+
+@pytest.mark.parametrize("shape", [(1, 32, 32), (3, 32, 64), (1, 160, 96)])
+def test_dbnet_minimum_and_odd_shapes_match_oracle(shape):
+    from ocr_vi_invoice_amd import DBNetPP, weights
+    from oracle import dbnet_cpu
+    N, H, W = shape
+    sd = weights.make_det_state_dict(seed=9)
+    x = torch.randn(N, 3, H, W, generator=torch.Generator().manual_seed(H + W))
+    ref = dbnet_cpu.forward(sd, x)
+    out = DBNetPP(pretrained=False, state_dict=sd, dtype="f32")(x.cuda())
+    for k in ("binary", "thresh", "thresh_binary"):
+        np.testing.assert_allclose(out[k].cpu().numpy(), ref[k].numpy(), atol=1e-3, err_msg=k)
