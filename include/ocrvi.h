@@ -113,6 +113,9 @@ int ocrvi_ctc_greedy(int device, const float* log_probs, int T, int B, int C, in
 /* Replaces the detection input normalisation of src/pipeline/pipeline2.py:312-314: images uint8 HWC
  * [N,H,W,3] (device) -> float32 NCHW [N,3,H,W] = ((v/255 as float32) - mean) / std evaluated in float64. */
 int ocrvi_normalize_u8(int device, const uint8_t* images, int N, int H, int W, float* out, void* stream);
+/* Replaces the cv2.resize call of resize_image_for_det (src/pipeline/pipeline2.py:33-40): uint8 HWC [src_h,src_w,3] ->
+ * uint8 HWC [dst_h,dst_w,3], OpenCV's 8-bit INTER_LINEAR (fixed-point) arithmetic. */
+int ocrvi_resize_u8(int device, const uint8_t* src, int src_h, int src_w, uint8_t* dst, int dst_h, int dst_w, void* stream);
 /* Replaces crop_image (src/det/test.py:123-130, box already reduced to its clamped bounding rect) followed by
  * preprocess_for_recognition (src/pipeline/pipeline2.py:92-128) for a batch of crops.  images uint8 HWC
  * [n_img,H,W,3]; boxes int32 [B,5] = (image index, x, y, w, h) in pixels, inside the image; out float32

@@ -86,9 +86,46 @@ __global__ void crop_resize_normalize_kernel(const uint8_t* __restrict__ images,
     }
 }
 
+// cv2.resize(img, (dw, dh)) with the default INTER_LINEAR on uint8 HWC (resize_image_for_det, pipeline2.py:33-40)
+__global__ void resize_u8_kernel(const uint8_t* __restrict__ src, int sh, int sw, uint8_t* __restrict__ dst, int dh, int dw) {
+    const size_t total = (size_t)dh * dw;
+    const bool area2 = (sw == 2 * dw && sh == 2 * dh);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % dw), y = (int)(i / dw);
+        const size_t rs = (size_t)sw * 3;
+        int v[3];
+        if (area2) {
+            const uint8_t* p0 = src + (size_t)(2 * y) * rs + (size_t)(2 * x) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[c] = (p0[c] + p0[3 + c] + p0[rs + c] + p0[rs + 3 + c] + 2) >> 2;
+        } else {
+            const AxisCoef ax = axis_coef(x, sw, dw), ay = axis_coef(y, sh, dh);
+            const uint8_t *r0 = src + (size_t)ay.s0 * rs, *r1 = src + (size_t)ay.s1 * rs;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int h0 = r0[ax.s0 * 3 + c] * ax.a0 + r0[ax.s1 * 3 + c] * ax.a1;
+                const int h1 = r1[ax.s0 * 3 + c] * ax.a0 + r1[ax.s1 * 3 + c] * ax.a1;
+                v[c] = (((ay.a0 * (h0 >> 4)) >> 16) + ((ay.a1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dst[i * 3 + c] = (uint8_t)v[c];
+    }
+}
+
 }  // namespace ocrvi
 
 using namespace ocrvi;
+
+extern "C" int ocrvi_resize_u8(int device, const uint8_t* src, int src_h, int src_w, uint8_t* dst, int dst_h, int dst_w, void* stream) {
+    OCRVI_CHECK(src && dst && src_h > 0 && src_w > 0 && dst_h > 0 && dst_w > 0, OCRVI_EINVAL, "resize_u8: bad argument");
+    OCRVI_HIP(hipSetDevice(device));
+    const size_t total = (size_t)dst_h * dst_w;
+    const int grid = (int)std::min<size_t>((total + 255) / 256, 16384);
+    hipLaunchKernelGGL(resize_u8_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, src_h, src_w, dst, dst_h, dst_w);
+    OCRVI_HIP(hipGetLastError());
+    return OCRVI_OK;
+}
 
 extern "C" int ocrvi_normalize_u8(int device, const uint8_t* images, int N, int H, int W, float* out, void* stream) {
     OCRVI_CHECK(images && out && N > 0 && H > 0 && W > 0, OCRVI_EINVAL, "normalize_u8: bad argument");

@@ -2,7 +2,8 @@
 
 Same names and argument meaning as the reference for the pieces either side of the two models:
 ``load_detection_model`` (:43), ``load_recognition_model`` (:72), ``preprocess_for_recognition`` (:92), ``recognize_text`` (:131),
-``recognize_text_batch`` (:144), ``crop_image`` (src/det/test.py:123) plus ``normalize_for_det`` (the inline code at :312-314).
+``recognize_text_batch`` (:144), ``resize_image_for_det`` (:33), ``crop_image`` (src/det/test.py:123) plus ``normalize_for_det`` (the
+inline code at :312-314).
 Image resizing and crop pre-processing run on the GPU (ocrvi_crop_resize_normalize / ocrvi_normalize_u8).
 
 Not provided yet: ``DBPostProcessor`` (src/det/test.py:46-106; cv2.findContours / approxPolyDP / pyclipper) -- the next row in
@@ -35,6 +36,21 @@ def load_recognition_model(model_path: str, device: str = "cuda:0", variant: str
 def _dev_index(device) -> int:
     d = torch.device(device)
     return d.index if d.index is not None else torch.cuda.current_device()
+
+
+def resize_image_for_det(image, image_size: int = 640):
+    """pipeline2.py:33-40: scale the longer side to ``image_size``, round both sides to multiples of 32, cv2.resize (bilinear).
+    ``image``: uint8 HWC numpy array or device tensor.  Returns (resized uint8 HWC device tensor, (scale_h, scale_w))."""
+    img = image if isinstance(image, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(image))
+    img = img.cuda().contiguous() if not img.is_cuda else img.contiguous()
+    h, w = img.shape[:2]
+    scale = image_size / max(h, w)
+    new_h = int(np.round(h * scale / 32) * 32)
+    new_w = int(np.round(w * scale / 32) * 32)
+    out = torch.empty((new_h, new_w, 3), dtype=torch.uint8, device=img.device)
+    stream = torch.cuda.current_stream(img.device).cuda_stream
+    _lib.check(_lib.load().ocrvi_resize_u8(_dev_index(img.device), img.data_ptr(), h, w, out.data_ptr(), new_h, new_w, stream))
+    return out, (new_h / h, new_w / w)
 
 
 def normalize_for_det(images_u8: torch.Tensor) -> torch.Tensor:

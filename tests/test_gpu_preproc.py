@@ -47,3 +47,37 @@ def test_crop_resize_normalize_matches_oracle(oh, ow):
         ref = P.preprocess_for_recognition(imgs[i][y:y + h, x:x + w], (oh, ow))
         # integer pixel values are bit-exact; the float32 normalisation may differ by 1 ulp between numpy and the device
         np.testing.assert_allclose(got[k], ref, rtol=0, atol=3e-7, err_msg=f"box {k} {boxes[k]}")
+
+
+@pytest.mark.parametrize("hw,size", [((700, 500), 640), ((1920, 2560), 960), ((333, 1000), 960), ((640, 640), 320)])
+def test_resize_image_for_det_matches_oracle(hw, size):
+    """pipeline2.py:33-40 (sides rounded to multiples of 32; exact-2x case takes the area path)."""
+    from ocr_vi_invoice_amd import pipeline
+    from oracle import preproc_cpu as P
+    rng = np.random.default_rng(hw[0])
+    img = rng.integers(0, 256, size=hw + (3,), dtype=np.uint8)
+    out, (sh, sw) = pipeline.resize_image_for_det(img, size)
+    scale = size / max(hw)
+    nh, nw = int(np.round(hw[0] * scale / 32) * 32), int(np.round(hw[1] * scale / 32) * 32)
+    assert out.shape == (nh, nw, 3) and nh % 32 == 0 and nw % 32 == 0
+    assert (sh, sw) == (nh / hw[0], nw / hw[1])
+    np.testing.assert_array_equal(out.cpu().numpy(), P.resize_linear_u8(img, (nw, nh)))
+
+
+def test_checkpoint_files_load_like_the_reference_loaders(tmp_path):
+    """pipeline2.py:43-89: dict-wrapped or bare state_dicts, 'module.'-prefixed keys; read with weights_only=True."""
+    from ocr_vi_invoice_amd import SVTRv2, DBNetPP, pipeline, synth, weights
+    rsd = weights.make_rec_state_dict("tiny", seed=77)
+    p1 = tmp_path / "rec.pth"
+    torch.save({"model_state_dict": {"module." + k: v for k, v in rsd.items()}, "epoch": 12, "best_acc": 0.3, "variant": "tiny"}, p1)
+    a = pipeline.load_recognition_model(str(p1), "cuda:0", variant="tiny", dtype="f32")
+    b = SVTRv2("tiny", state_dict=rsd, dtype="f32")
+    x = torch.from_numpy(synth.pad_crop_batch(synth.make_crops(1, 3, 32, 128), 32, 128)).cuda()
+    assert torch.equal(a(x), b(x))
+    dsd = weights.make_det_state_dict(seed=77)
+    p2 = tmp_path / "det.pth"
+    torch.save(dsd, p2)                                  # bare state_dict
+    d1 = pipeline.load_detection_model(str(p2), "cuda:0", dtype="bf16")
+    d2 = DBNetPP(pretrained=False, state_dict=dsd, dtype="bf16")
+    xi = torch.randn(1, 3, 64, 64, device="cuda")
+    assert torch.equal(d1(xi)["binary"], d2(xi)["binary"])
