@@ -123,6 +123,13 @@ int ocrvi_resize_u8(int device, const uint8_t* src, int src_h, int src_w, uint8_
 int ocrvi_crop_resize_normalize(int device, const uint8_t* images, int n_img, int H, int W, const int32_t* boxes, int B,
                                 int out_h, int out_w, float* out, void* stream);
 
+/* Replaces DBPostProcessor(thresh, box_thresh, max_candidates, unclip_ratio).__call__ with .min_area (src/det/test.py:46-106) on a HOST
+ * probability map prob[H*W] (the reference also runs this stage on the CPU after `.cpu().numpy()`, pipeline2.py:320-321).
+ * Output: the unclipped polygons as int32 (x, y) pairs in points[2*cap_points]; box i owns points box_offsets[i] .. box_offsets[i+1]
+ * (box_offsets has cap_boxes+1 entries); scores[i] is its box_score_fast value; *n_boxes the number of boxes, in the reference's order. */
+int ocrvi_db_postprocess(const float* prob, int H, int W, float thresh, float box_thresh, int max_candidates, float unclip_ratio,
+                         float min_area, int32_t* points, int cap_points, int32_t* box_offsets, float* scores, int cap_boxes, int* n_boxes);
+
 /* ------------------------------------------------------------------------------------------------
  * Kernel-level test/bench hooks (same kernels the models launch; used by tests/ and bench.py for
  * per-kernel parity and roofline timing).

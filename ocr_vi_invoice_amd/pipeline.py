@@ -6,12 +6,15 @@ Same names and argument meaning as the reference for the pieces either side of t
 inline code at :312-314).
 Image resizing and crop pre-processing run on the GPU (ocrvi_crop_resize_normalize / ocrvi_normalize_u8).
 
-Not provided yet: ``DBPostProcessor`` (src/det/test.py:46-106; cv2.findContours / approxPolyDP / pyclipper) -- the next row in
-DESIGN.md section 7.  A caller that has cv2 keeps using the reference's own post-processor on ``det(x)['binary']``.
+``DBPostProcessor`` (src/det/test.py:46-106) is the host C++ implementation behind ``ocrvi_db_postprocess``; like the reference's, it works on
+the probability map after the device->host copy.  cv2 / pyclipper / shapely are absent from the build container, so its agreement with
+those libraries is unpinned; it is checked bit-for-bit against the independent statement in oracle/dbpost_cpu.py.
 """
 from __future__ import annotations
 
 from typing import List, Sequence, Tuple
+
+import ctypes
 
 import numpy as np
 import torch
@@ -63,6 +66,60 @@ def normalize_for_det(images_u8: torch.Tensor) -> torch.Tensor:
     out = torch.empty((N, 3, H, W), dtype=torch.float32, device=images_u8.device)
     stream = torch.cuda.current_stream(images_u8.device).cuda_stream
     _lib.check(_lib.load().ocrvi_normalize_u8(_dev_index(images_u8.device), images_u8.data_ptr(), N, H, W, out.data_ptr(), stream))
+    return out
+
+
+class DBPostProcessor:
+    """src/det/test.py:44-106: probability map -> unclipped text polygons + scores.  Same constructor, attributes and call signature."""
+
+    def __init__(self, thresh=0.3, box_thresh=0.6, max_candidates=1000, unclip_ratio=1.5):
+        self.thresh = thresh
+        self.box_thresh = box_thresh
+        self.max_candidates = max_candidates
+        self.unclip_ratio = unclip_ratio
+        self.min_size = 3
+        self.min_area = 10
+
+    def __call__(self, pred, is_output_polygon=False):
+        """pred: (1, H, W) float array or tensor (a device tensor is copied to the host, as pipeline2.py:320 does).
+        Returns (boxes, scores): boxes[i] is an (n_i, 2) int64 array of polygon vertices, scores[i] a float."""
+        if isinstance(pred, torch.Tensor):
+            pred = pred.detach().float().cpu().numpy()
+        pred = np.asarray(pred)
+        if pred.ndim == 3:
+            pred = pred[0]
+        if pred.ndim != 2:
+            raise ValueError(f"DBPostProcessor expects (1, H, W) or (H, W), got shape {pred.shape}")
+        prob = np.ascontiguousarray(pred, dtype=np.float32)
+        H, W = prob.shape
+        lib = _lib.load()
+        cap_boxes = max(int(self.max_candidates), 1)
+        cap_points = 4 * (H + W) + 4096
+        while True:
+            points = np.empty((cap_points, 2), np.int32)
+            offs = np.empty(cap_boxes + 1, np.int32)
+            scores = np.empty(cap_boxes, np.float32)
+            n = ctypes.c_int32(0)
+            rc = lib.ocrvi_db_postprocess(prob.ctypes.data, H, W, float(self.thresh), float(self.box_thresh), int(self.max_candidates),
+                                          float(self.unclip_ratio), float(self.min_area), points.ctypes.data, cap_points, offs.ctypes.data,
+                                          scores.ctypes.data, cap_boxes, ctypes.byref(n))
+            if rc == -3 and cap_points < (1 << 28):
+                cap_points *= 4          # more polygon vertices than guessed: retry with room
+                continue
+            _lib.check(rc)
+            break
+        boxes = [points[offs[i]:offs[i + 1]].astype(np.int64) for i in range(n.value)]
+        return boxes, [float(v) for v in scores[:n.value]]
+
+
+def rescale_boxes(boxes, scale_w: float, scale_h: float) -> List[np.ndarray]:
+    """pipeline2.py:324-328: the in-place true-divide into the integer array truncates toward zero; then ``astype(int32)``."""
+    out = []
+    for box in boxes:
+        b = np.asarray(box).astype(np.int64)
+        b[:, 0] = np.trunc(b[:, 0] / scale_w)
+        b[:, 1] = np.trunc(b[:, 1] / scale_h)
+        out.append(b.astype(np.int32))
     return out
 
 
