@@ -3,7 +3,7 @@
 Same names and argument meaning as the reference for the pieces either side of the two models:
 ``load_detection_model`` (:43), ``load_recognition_model`` (:72), ``preprocess_for_recognition`` (:92), ``recognize_text`` (:131),
 ``recognize_text_batch`` (:144), ``resize_image_for_det`` (:33), ``crop_image`` (src/det/test.py:123) plus ``normalize_for_det`` (the
-inline code at :312-314).
+inline code at :312-314), ``rescale_boxes`` (:324-328) and ``detect_and_recognize`` (steps 2-3 of the per-image loop, :306-352).
 Image resizing and crop pre-processing run on the GPU (ocrvi_crop_resize_normalize / ocrvi_normalize_u8).
 
 ``DBPostProcessor`` (src/det/test.py:46-106) is the host C++ implementation behind ``ocrvi_db_postprocess``; like the reference's, it works on
@@ -177,3 +177,31 @@ def recognize_text_batch(model: SVTRv2, crops: List[np.ndarray], device: str = "
         ts = [preprocess_for_recognition(c, img_size, device) for c in crops[i:i + batch_size]]
         texts.extend(model.decode_greedy(torch.stack(ts)))
     return texts
+
+
+def detect_and_recognize(original_image, det_model, rec_model, post_processor: DBPostProcessor, device: str = "cuda:0", det_size: int = 640,
+                         rec_size: Tuple[int, int] = (32, 256), rec_batch_size: int = 64):
+    """Steps 2 and 3 of the reference's per-image loop (pipeline2.py:306-352) with every stage on this library: resize + normalise on the
+    device -> ``det_model`` -> ``post_processor`` on the host copy of the binary map -> boxes rescaled to the original image -> the
+    bounding rectangle of each box cropped, resized and normalised on the device straight from the uploaded page -> ``rec_model`` greedy
+    CTC in batches of ``rec_batch_size``.  ``original_image``: RGB uint8 HxWx3 (numpy or device tensor).
+    Returns (rescaled_boxes [int32 (n_i, 2)], scores, texts); empty crops decode the all-zero tensor as pipeline2.py:154-156 does."""
+    page = original_image if isinstance(original_image, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(original_image))
+    page = page.to(device).contiguous()
+    h, w = page.shape[:2]
+    resized, (scale_h, scale_w) = resize_image_for_det(page, det_size)
+    det_preds = det_model(normalize_for_det(resized))
+    pred_binary = det_preds["binary"] if isinstance(det_preds, dict) else det_preds
+    boxes, scores = post_processor(pred_binary[0])
+    rescaled = rescale_boxes(boxes, scale_w, scale_h)
+    rects = [(0,) + crop_rect((h, w), b) for b in rescaled]
+    texts: List[str] = []
+    for i in range(0, len(rects), rec_batch_size):
+        chunk = rects[i:i + rec_batch_size]
+        live = [r for r in chunk if r[3] > 0 and r[4] > 0]
+        batch = torch.zeros((len(chunk), 3) + tuple(rec_size), device=page.device)
+        if live:
+            idx = torch.as_tensor([j for j, r in enumerate(chunk) if r[3] > 0 and r[4] > 0], device=page.device)
+            batch[idx] = preprocess_crops(page[None], live, rec_size)
+        texts.extend(rec_model.decode_greedy(batch))
+    return rescaled, scores, texts
