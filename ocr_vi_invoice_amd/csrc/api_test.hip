@@ -126,11 +126,13 @@ extern "C" int ocrvi_test_conv(int device, int dtype, const float* x, const floa
     PackedConv pc = pack_conv(weight_host, bias_host, Co, C / groups, ksize, ksize, groups, amode, dtype);
     OCRVI_TRY(upload_packed(st, pc, amode, &L));
     void *xn = nullptr, *yn = nullptr;
-    OCRVI_TRY(sc.alloc((size_t)N * H * W * C * dtype_size(dtype), &xn));
+    // OCRVI_TEST_PADC=n (timing experiments only; the result is then meaningless): give the activation rows a channel stride of C + n
+    const int padc = getenv("OCRVI_TEST_PADC") ? atoi(getenv("OCRVI_TEST_PADC")) : 0;
+    OCRVI_TRY(sc.alloc((size_t)N * H * W * (C + padc) * dtype_size(dtype), &xn));
     OCRVI_TRY(sc.alloc((size_t)N * Ho * Wo * Co * dtype_size(dtype), &yn));
     OCRVI_TRY(to_nhwc(dtype, x, xn, N, C, H * W, sc.s));
     Runner r(dtype, sc.s, (void*)256, 0);
-    Tensor tx; tx.p = xn; tx.n = N; tx.h = H; tx.w = W; tx.c = C;
+    Tensor tx; tx.p = xn; tx.n = N; tx.h = H; tx.w = W; tx.c = C + padc;
     Tensor ty; ty.p = yn; ty.n = N; ty.h = Ho; ty.w = Wo; ty.c = Co;
     ConvOpts o;
     o.sh = sh; o.sw = sw; o.pad = pad; o.act = act;

@@ -54,6 +54,27 @@ static int launch_ring_bm(const ConvParams& p, hipStream_t stream) {
     }
     const int total = cdiv(p.M, BM) * (p.Np / 128);
     const int grid = cdiv(total, cdiv(total, n_cu));  // one persistent workgroup per CU, equal tile counts
+    static const bool prof = getenv("OCRVI_RING_PROF") && atoi(getenv("OCRVI_RING_PROF"));
+    if (prof) {  // development aid: cycle breakdown per phase, printed per launch (synchronises)
+        auto pk = gemm_ring_kernel<T, BM, true>;
+        static unsigned long long* dbuf = nullptr;
+        if (!dbuf) {
+            OCRVI_HIP(hipMalloc((void**)&dbuf, 64));
+            OCRVI_HIP(hipFuncSetAttribute((const void*)pk, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        }
+        OCRVI_HIP(hipMemsetAsync(dbuf, 0, 64, stream));
+        ConvParams q = p;
+        q.out2 = dbuf;
+        hipLaunchKernelGGL(pk, dim3(grid), dim3(512), smem, stream, q);
+        unsigned long long h[4];
+        OCRVI_HIP(hipMemcpyAsync(h, dbuf, 32, hipMemcpyDeviceToHost, stream));
+        OCRVI_HIP(hipStreamSynchronize(stream));
+        const double w = 8.0 * grid, tot = (double)(h[0] + h[1] + h[2] + h[3]);
+        fprintf(stderr, "ring BM%d M%d N%d K%d grid %d tiles %d nk %d: cycles/wave wait %.0f issue %.0f mma %.0f epi %.0f (%.0f%% %.0f%% %.0f%% %.0f%%)\n", BM,
+                p.M, p.N_g, p.Kp, grid, total, p.Kp / (int)(128 / sizeof(T)), h[0] / w, h[1] / w, h[2] / w, h[3] / w, 100 * h[0] / tot, 100 * h[1] / tot,
+                100 * h[2] / tot, 100 * h[3] / tot);
+        return OCRVI_OK;
+    }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, stream, p);
     OCRVI_HIP(hipGetLastError());
     return OCRVI_OK;

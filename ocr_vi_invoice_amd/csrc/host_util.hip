@@ -193,8 +193,12 @@ bool gemm_ring_eligible(const ConvParams& p, int amode, int dtype) {
     const int esz = (int)dtype_size(dtype), bke = conv_bke(dtype);
     if (p.Cin_g % bke != 0 || p.Kp != p.Cin_g || p.N_g < 128 || p.N_g % 4 != 0 || p.Np % 128 != 0) return false;
     if (((size_t)p.cin_off * esz) % 16 != 0 || ((size_t)p.Cin * esz) % 16 != 0 || ((uintptr_t)p.x & 15) != 0) return false;
-    if (p.ldo % 4 != 0 || p.out_coff % 4 != 0 || ((uintptr_t)p.out & 15) != 0) return false;
-    if (p.res_mode == RES_SAME && (p.ldr % 4 != 0 || ((uintptr_t)p.res & 15) != 0)) return false;
+    // 16-byte epilogue accesses: 4 fp32 or 8 16-bit channels
+    const bool of32 = p.out_f32 || esz == 4, rf32 = p.res_f32 || esz == 4;
+    const int og = of32 ? 4 : 8;
+    if (p.N_g % og != 0 || p.ldo % og != 0 || p.out_coff % og != 0 || ((uintptr_t)p.out & 15) != 0) return false;
+    if (p.res_mode == RES_SAME && (rf32 != of32 || p.ldr % og != 0 || ((uintptr_t)p.res & 15) != 0)) return false;
+    if (p.bias && ((uintptr_t)p.bias & 15) != 0) return false;
     return true;
 }
 
