@@ -139,19 +139,21 @@ template <> struct Mma<f16_t> {
 // conflict-free under the gfx950 lane-group / 64-bank rule (checked by simulation).
 __device__ __forceinline__ int swz128(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 2); }
 
-// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e. fp32 round-off level): 1 rcp + 1 exp + 6 fma instead of
-// libm erff's ~50-instruction polynomial ladder, which made the GELU epilogue several times the MFMA main loop.
-__device__ __forceinline__ float erf_as(float x) {
+// Exact (erf) GELU = x * Phi(x) with erfc by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e. fp32 round-off level):
+//   z = |x| / sqrt(2),  t = 1 / (1 + p z),  erfc(z) = t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) exp(-z^2),
+//   Phi(x) = 1 - erfc(z) / 2 for x >= 0, erfc(z) / 2 otherwise.
+// One v_rcp_f32 + one v_exp_f32 (both 1 ulp) + 6 fma: libm erff's polynomial ladder and a correctly rounded 1/x (v_div_scale /
+// v_div_fmas / v_div_fixup) each made the GELU epilogue cost several MFMA main loops.
+__device__ __forceinline__ float gelu_erf(float x) {
     const float ax = fabsf(x);
-    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float r = 1.0f - p * t * __expf(-ax * ax);
-    return copysignf(r, x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
+    float q = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+    q = fmaf(q, t, 0.5f * 1.421413741f);
+    q = fmaf(q, t, 0.5f * -0.284496736f);
+    q = fmaf(q, t, 0.5f * 0.254829592f);
+    const float h = q * t * __builtin_amdgcn_exp2f(x * x * (-0.5f * 1.44269504088896340736f));  // erfc(z) / 2
+    return x * (x >= 0.f ? 1.0f - h : h);
 }
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 // XCD-aware block remap (cdna_hip_programming.md T1, bijective form): consecutive logical tiles land on one XCD.

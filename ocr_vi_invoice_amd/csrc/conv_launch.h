@@ -4,6 +4,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+
 #include "conv_gemm.h"
 #include "gemm_ring.h"
 
@@ -37,26 +39,19 @@ static int launch_tile(const ConvParams& p, hipStream_t stream) {
     return OCRVI_OK;
 }
 
-template <typename T, int BM>
-static int launch_ring_bm(const ConvParams& p, hipStream_t stream) {
-    constexpr int smem = 3 * (BM + 128) * 128;
-    auto kern = gemm_ring_kernel<T, BM>;
+template <typename T, int BM, int NW, int SPS, bool F32O>
+static int launch_ring_f(const ConvParams& p, int grid, hipStream_t stream) {
+    constexpr int smem = 3 * (BM + 128) * 128 + 512;  // ring + bias
+    auto kern = gemm_ring_kernel<T, BM, NW, SPS, F32O>;
     static bool attr_done = false;
-    static int n_cu = 0;
     if (!attr_done) {
         OCRVI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        int dev = 0;
-        hipDeviceProp_t prop;
-        OCRVI_HIP(hipGetDevice(&dev));
-        OCRVI_HIP(hipGetDeviceProperties(&prop, dev));
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         attr_done = true;
     }
-    const int total = cdiv(p.M, BM) * (p.Np / 128);
-    const int grid = cdiv(total, cdiv(total, n_cu));  // one persistent workgroup per CU, equal tile counts
+#ifdef OCRVI_RING_PROF_BUILD
     static const bool prof = getenv("OCRVI_RING_PROF") && atoi(getenv("OCRVI_RING_PROF"));
     if (prof) {  // development aid: cycle breakdown per phase, printed per launch (synchronises)
-        auto pk = gemm_ring_kernel<T, BM, true>;
+        auto pk = gemm_ring_kernel<T, BM, NW, SPS, F32O, true>;
         static unsigned long long* dbuf = nullptr;
         if (!dbuf) {
             OCRVI_HIP(hipMalloc((void**)&dbuf, 64));
@@ -65,28 +60,54 @@ static int launch_ring_bm(const ConvParams& p, hipStream_t stream) {
         OCRVI_HIP(hipMemsetAsync(dbuf, 0, 64, stream));
         ConvParams q = p;
         q.out2 = dbuf;
-        hipLaunchKernelGGL(pk, dim3(grid), dim3(512), smem, stream, q);
+        hipLaunchKernelGGL(pk, dim3(grid), dim3(NW * 64), smem, stream, q);
         unsigned long long h[4];
         OCRVI_HIP(hipMemcpyAsync(h, dbuf, 32, hipMemcpyDeviceToHost, stream));
         OCRVI_HIP(hipStreamSynchronize(stream));
-        const double w = 8.0 * grid, tot = (double)(h[0] + h[1] + h[2] + h[3]);
-        fprintf(stderr, "ring BM%d M%d N%d K%d grid %d tiles %d nk %d: cycles/wave wait %.0f issue %.0f mma %.0f epi %.0f (%.0f%% %.0f%% %.0f%% %.0f%%)\n", BM,
-                p.M, p.N_g, p.Kp, grid, total, p.Kp / (int)(128 / sizeof(T)), h[0] / w, h[1] / w, h[2] / w, h[3] / w, 100 * h[0] / tot, 100 * h[1] / tot,
-                100 * h[2] / tot, 100 * h[3] / tot);
+        const double w = (double)NW * grid, tot = (double)(h[0] + h[1] + h[2] + h[3]);
+        fprintf(stderr, "ring BM%d NW%d SPS%d M%d N%d K%d grid %d nk %d act %d res %d f32o %d: cycles/wave wait %.0f issue %.0f mma %.0f epi %.0f (%.0f%% %.0f%% %.0f%% %.0f%%)\n",
+                BM, NW, SPS, p.M, p.N_g, p.Kp, grid, p.Kp / (int)(128 / sizeof(T)), p.act, p.res_mode, p.out_f32, h[0] / w, h[1] / w, h[2] / w, h[3] / w,
+                100 * h[0] / tot, 100 * h[1] / tot, 100 * h[2] / tot, 100 * h[3] / tot);
         return OCRVI_OK;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, stream, p);
+#endif
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), smem, stream, p);
     OCRVI_HIP(hipGetLastError());
     return OCRVI_OK;
+}
+
+template <typename T, int BM, int NW, int SPS>
+static int launch_ring_cfg(const ConvParams& p, int grid, hipStream_t stream) {
+    if constexpr (sizeof(T) == 4) return launch_ring_f<T, BM, NW, SPS, true>(p, grid, stream);
+    else if (p.out_f32) return launch_ring_f<T, BM, NW, SPS, true>(p, grid, stream);
+    else return launch_ring_f<T, BM, NW, SPS, false>(p, grid, stream);
 }
 
 template <typename T>
 int launch_gemm_ring(const ConvParams& p_in, hipStream_t stream) {
     ConvParams p = p_in;
     OCRVI_TRY(ring_pages(&p.zero_page, &p.dump_page));
-    // 256-row tiles when that still gives every CU work; 128-row tiles for short M
-    if (cdiv(p.M, 256) * (p.Np / 128) >= 192) return launch_ring_bm<T, 256>(p, stream);
-    return launch_ring_bm<T, 128>(p, stream);
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        OCRVI_HIP(hipGetDevice(&dev));
+        OCRVI_HIP(hipGetDeviceProperties(&prop, dev));
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int ntiles = p.Np / 128, nk = p.Kp / (int)(128 / sizeof(T));
+    OCRVI_CHECK(ntiles >= 1 && ntiles <= n_cu && nk >= 1, OCRVI_EINVAL, "gemm_ring: Np=%d Kp=%d out of range", p.Np, p.Kp);
+    // 256-row tiles (4 slice groups riding on the next tile's first 4 K-steps) when K is deep enough for that and M still gives every
+    // CU work; otherwise 128-row tiles (one group)
+    const int bm = (nk >= 4 && cdiv(p.M, 256) * ntiles >= 192) ? 256 : 128;
+    // one persistent workgroup per CU; a workgroup keeps its column tile, so the grid is Gm row-tile lanes x ntiles, with Gm chosen
+    // for equal row-tile counts
+    const int mtiles = cdiv(p.M, bm);
+    int gm = std::min(mtiles, std::max(1, n_cu / ntiles));
+    gm = cdiv(mtiles, cdiv(mtiles, gm));
+    const int grid = gm * ntiles;
+    if (bm == 256) return launch_ring_cfg<T, 256, 8, 1>(p, grid, stream);
+    return launch_ring_cfg<T, 128, 8, 2>(p, grid, stream);
 }
 
 template <typename T, int AMODE>

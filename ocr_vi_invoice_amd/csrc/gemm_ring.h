@@ -4,7 +4,9 @@
 // Why a second kernel: conv_gemm stages operands through registers, so its prefetch depth is one K-step and a tile's prologue and
 // epilogue latency is only hidden by other workgroups.  Here operands go global -> LDS directly (global_load_lds_dwordx4, no staging
 // VGPRs) into a 3-stage ring that keeps streaming ACROSS tile boundaries: the next tile's first two K-steps are in flight while the
-// current tile's epilogue runs.  256x128 (or 128x128) tile, 8 waves (4 along M x 2 along N), one workgroup per CU, persistent.
+// previous tile's epilogue runs.  One persistent workgroup per CU: a 256x128 tile on 4 waves (2 x 2, one per SIMD, 128x64 each: the
+// wave then owns the SIMD's whole 512-entry register file, which the parked accumulators of the deferred epilogue need), or a
+// 128x128 tile on 8 waves (4 x 2) for short M.
 //
 // Protocol per K-step s (slot = s % 3), every wave:
 //   s_waitcnt vmcnt(N)   own DMAs of stage s have landed        (N counts exactly the younger VMEM ops: stage s+1's DMAs and, right
@@ -21,34 +23,60 @@
 
 namespace ocrvi {
 
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+// 16 bytes per lane from (uniform base + per-lane 32-bit offset) to LDS at lds_dst + lane * 16
+__device__ __forceinline__ void glds16(const char* sbase, unsigned voff, unsigned lds_dst) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst)
                  : "memory");
+}
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {  // tell the compiler the pointer is wave-uniform
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const char*)(((unsigned long long)hi << 32) | lo);
 }
 template <int N> __device__ __forceinline__ void wait_vm_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void gload16(u32x4& dst, const void* gsrc) {  // asynchronous: dst is valid only after wait_vm_only + bind16
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(gsrc) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vm_only() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void bind16(u32x4& r) { asm volatile("" : "+v"(r)); }  // every later use of r is ordered after this point
+
 // Epilogue layout.  fp32 output: MFMA block a is channels 16a .. 16a+15, lane (lr, g) holds 4 consecutive ones -> a 16-byte access
 // per lane, 64 contiguous bytes per pixel row per instruction.  16-bit output: the weight fragment of block a reads tile row
 // 32*(a>>1) + 8*(lr>>2) + 4*(a&1) + (lr&3) of the wave's 64 instead (a permutation of the output channels, conflict-free under the
 // same XOR swizzle), so lane (lr, g) ends up with channels [8g, 8g+8) and [32+8g, 32+8g+8): again 16 bytes per lane and 64
-// contiguous bytes per row per instruction.  A residual has the output's element type (checked by gemm_ring_eligible).  Bias and residual are fetched with plain loads at the top of the tile's LAST K-step (all issued back to back, after
-// that step's DMAs) and consumed after its MFMAs: one exposed memory round trip per tile at most, instead of one per fragment.
+// contiguous bytes per row per instruction.  A residual has the output's element type (checked by gemm_ring_eligible).
 //
-// PROF (development only, OCRVI_RING_PROF=1): every wave accumulates shader-clock cycles spent in wait+barrier / DMA issue /
-// ds_read+MFMA / epilogue and adds them into p.out2 (uint64[4]) at exit.
-template <typename T, int BM, bool PROF = false>
-__global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const ConvParams p) {
+// Deferred epilogue.  The kernel is bound by the latency of its operand stream, not by MFMA issue, so a tile's epilogue (bias,
+// activation, residual, stores) is not run at the tile boundary but in NGRP = MI / SPS slice groups of SPS 16-row slices, one group
+// in each of the first NGRP K-steps of the NEXT tile -- in the shadow of DMAs that are in flight anyway.  Tiles alternate between
+// two accumulator sets (the tile loop is unrolled by two and the first NGRP K-steps are peeled), so every register index is static
+// and nothing is copied.  A workgroup keeps one column tile (nt) for its whole life, so its bias lives in registers.  Residual slices
+// are fetched by inline-asm loads issued before the step's DMAs and awaited with a counted vmcnt after the step's MFMAs
+// (compiler-visible loads would make hipcc wait vmcnt(0), draining the ring's DMAs: it cannot see them).  Host contract:
+// gridDim.x = Gm * (Np / 128) with Gm <= ceil(M / BM), and NGRP <= Kp / BKE (a tile's groups fit into the next tile's K-steps).
+//
+// PROF (development only, build with -DOCRVI_RING_PROF_BUILD, run with OCRVI_RING_PROF=1): every wave accumulates shader-clock
+// cycles spent in wait+barrier / issue / ds_read+MFMA / epilogue work and adds them into p.out2 (uint64[4]) at exit.
+template <int I> struct IC { static constexpr int value = I; };
+
+template <typename T, int BM, int NW, int SPS, bool F32O, bool PROF = false>
+__global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams p) {
     constexpr int EPC = TypeInfo<T>::EPC, BKE = 8 * EPC;
-    constexpr int BN = 128, TM = BM / 4, TN = 64, MI = TM / 16, NI = 4;
+    constexpr int BN = 128, WM = NW / 2, TM = BM / WM, TN = 64, MI = TM / 16, NI = 4;  // waves: WM along M x 2 along N
     constexpr int STAGE = (BM + BN) * 128, NSTAGE = 3;
-    constexpr int NA = BM / 64, NB = BN / 64;  // 1-KiB DMA pieces per wave per stage (8 rows x 128 B each)
+    constexpr int NA = BM / 8 / NW, NB = BN / 8 / NW;  // 1-KiB DMA pieces per wave per stage (8 rows x 128 B each)
     constexpr int G = NA + NB;                 // VMEM ops per wave per stage
-    constexpr int E32 = MI * 4, E16 = MI * 2;  // VMEM stores per wave per epilogue (unconditional; fp32 / 16-bit output)
+    constexpr int NGRP = MI / SPS;             // slice groups per tile
+    static_assert(MI % SPS == 0, "slice group size must divide the wave's row blocks");
+    constexpr int SG = F32O ? SPS * 4 : SPS * 2;  // VMEM stores per wave per slice group (unconditional)
+    static_assert(G + SG < 64, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 
@@ -56,69 +84,56 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const ConvParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int lr = lane & 15, g = lane >> 4;
-    const bool f32o = p.out_f32 || sizeof(T) == 4;                // output (and residual) element type: fp32 or T
+    constexpr bool f32o = F32O;                                   // output (and residual) element type: fp32 or T
+    static_assert(F32O || sizeof(T) == 2, "an fp32 GEMM has fp32 output");
+    const bool has_res = p.res_mode == RES_SAME;
     const int swa = swz128(lr);                                   // A rows: b*16 + lr
     // B rows of MFMA block a: 16-bit output: 32*(a>>1) + 4*(a&1) + brow (channel permutation, see above); fp32 output: 16*a + lr
     const int brow = f32o ? lr : 8 * (lr >> 2) + (lr & 3);
     const int swb = swz128(brow);                                 // (the per-a offset touches neither row bit 1 nor bit 3)
     const int foa0 = ((2 * g) ^ swa) << 4, foa1 = ((2 * g + 1) ^ swa) << 4;
     const int fob0 = ((2 * g) ^ swb) << 4, fob1 = ((2 * g + 1) ^ swb) << 4;
-    const int ntiles = p.Np / BN;
-    const int total = ((p.M + BM - 1) / BM) * ntiles;
+    const int ntiles = p.Np / BN, mtiles = (p.M + BM - 1) / BM;
     const int nk = p.Kp / BKE;
-    const int Gd = gridDim.x;
+    const int Gd = gridDim.x, Gm = Gd / ntiles;
+    const int wg = xcd_remap(blockIdx.x, Gd);
+    const int nt = wg % ntiles, mt0 = wg / ntiles;               // this workgroup: column tile nt, row tiles mt0, mt0 + Gm, ...
+    const int nb = nt * BN + wn * TN;                             // first output channel of this wave
     const char* const A = (const char*)p.x + (size_t)p.cin_off * sizeof(T);
-    const char* const Wt = (const char*)p.w;
-    const size_t lda_b = (size_t)p.Cin * sizeof(T), ldw_b = (size_t)p.Kp * sizeof(T);
+    const int lda_b = p.Cin * (int)sizeof(T), ldw_b = p.Kp * (int)sizeof(T);
 
-    // ---- DMA issue state: this lane's source pointers for its NA + NB pieces of the stage at the issue cursor
+    // ---- DMA issue state.  A piece is 8 rows x 128 B; piece i of this wave covers tile rows (i * NW + wave) * 8 + prow.  Sources are
+    // (uniform base of the tile row 0 at the stage's K offset) + (per-lane 32-bit offset): the XOR swizzle is applied on the source
+    // chunk, whose row bits 1 and 3 do not depend on i, so B needs one offset register and A one per piece (rows past M are clamped
+    // to the last valid row: what they produce is never stored).
     const int prow = lane >> 3;                                   // row inside an 8-row piece
-    const char* a_src[NA];
-    unsigned a_step[NA];                                          // 128, or 0 for rows past M (they read the zero page)
-    const char* b_src[NB];
-    int i_tile = xcd_remap(blockIdx.x, Gd), i_ks = 0;             // issue cursor
-    auto setup_issue = [&](int tile) {
-        const int mt = tile / ntiles, nt = tile - mt * ntiles;
+    const int chunk = (lane & 7) ^ swz128(wave * 8 + prow);       // source chunk that must land in LDS chunk (lane & 7)
+    const unsigned b_off = (unsigned)((wave * 8 + prow) * ldw_b + chunk * 16);
+    const char* const b_tile = uniform_ptr((const char*)p.w + (size_t)(nt * BN) * ldw_b);
+    unsigned a_off[NA];
+    const char* a_tile = nullptr;                                 // row 0 of the tile at the issue cursor
+    int i_mt = mt0, i_ks = 0;                                     // issue cursor
+    auto setup_issue = [&](int mt) {
+        a_tile = uniform_ptr(A + (size_t)mt * BM * lda_b);
+        const int last = p.M - 1 - mt * BM;                       // last valid row of this tile
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int row = (i * 8 + wave) * 8 + prow;            // row inside the A tile
-            const int m = mt * BM + row;
-            const int chunk = (lane & 7) ^ swz128(row);           // source chunk that must land in LDS chunk (lane & 7)
-            const bool ok = m < p.M;
-            a_src[i] = ok ? A + (size_t)m * lda_b + chunk * 16 : (const char*)p.zero_page + (lane & 7) * 16;
-            a_step[i] = ok ? 128u : 0u;
-        }
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int row = (i * 8 + wave) * 8 + prow;
-            const int chunk = (lane & 7) ^ swz128(row);
-            b_src[i] = Wt + (size_t)(nt * BN + row) * ldw_b + chunk * 16;
-        }
+        for (int i = 0; i < NA; ++i) a_off[i] = (unsigned)(min((i * NW + wave) * 8 + prow, last) * lda_b + chunk * 16);
     };
     auto issue_stage = [&](int slot) {  // DMA the stage at the issue cursor into ring slot `slot`, advance the cursor
         const unsigned base = lds0 + slot * STAGE;
+        const char* const ak = a_tile + (size_t)i_ks * 128;
+        const char* const bk = b_tile + (size_t)i_ks * 128;
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            glds16(a_src[i], __builtin_amdgcn_readfirstlane(base + (i * 8 + wave) * 1024));
-            a_src[i] += a_step[i];
-        }
+        for (int i = 0; i < NA; ++i) glds16(ak, a_off[i], __builtin_amdgcn_readfirstlane(base + (i * NW + wave) * 1024));
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            glds16(b_src[i], __builtin_amdgcn_readfirstlane(base + BM * 128 + (i * 8 + wave) * 1024));
-            b_src[i] += 128;
-        }
+        for (int i = 0; i < NB; ++i)
+            glds16(bk + (size_t)(i * NW * 8) * ldw_b, b_off, __builtin_amdgcn_readfirstlane(base + BM * 128 + (i * NW + wave) * 1024));
         if (++i_ks == nk) {
             i_ks = 0;
-            i_tile += Gd;
-            if (i_tile < total) setup_issue(i_tile);
+            i_mt += Gm;
+            if (i_mt < mtiles) setup_issue(i_mt);
         }
     };
-
-    f32x4 acc[NI][MI];
-#pragma unroll
-    for (int a = 0; a < NI; ++a)
-#pragma unroll
-        for (int b = 0; b < MI; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     auto activate = [&](float (&v)[4]) {
         if (p.act == ACT_RELU) {
@@ -129,123 +144,122 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const ConvParams p) {
             for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
         }
     };
-    // channel (inside the wave's 64) of acc[a][.][0] for this lane
     auto a_row = [&](int a) { return f32o ? 16 * a : 32 * (a >> 1) + 4 * (a & 1); };
+    // channel (inside the wave's 64) of acc[a][.][0] for this lane
     auto ch_of = [&](int a) { return f32o ? 16 * a + 4 * g : 32 * (a >> 1) + 8 * g + 4 * (a & 1); };
-    // ---- epilogue operands, fetched during the tile's last K-step.  Every load is unconditional (out-of-range lanes read the zero
-    // page) so that the compiler issues them back to back instead of branching around each one.
-    float4 bias_r[NI];
-    uint4 res_r[MI][4];  // fp32 residual: [b][a] = 4 floats; 16-bit residual: [b][j] = 8 elements, j < 2
-    auto prefetch_epi = [&](int tile) {
-        const int mt = tile / ntiles, nt = tile - mt * ntiles;
-        const int nb = nt * BN + wn * TN;
-        if (p.bias) {
+
+    // ---- per-workgroup constant of the epilogue: the bias of the workgroup's 128 channels, parked in LDS behind the ring
+    float* const bias_s = (float*)(smem + NSTAGE * STAGE);
+    if (tid < BN) bias_s[tid] = (p.bias && nt * BN + tid < p.N_g) ? p.bias[nt * BN + tid] : 0.f;
+    __syncthreads();  // (also drains the bias loads: no VMEM op is in flight when the ring starts)
+
+    typedef f32x4 Acc[NI][MI];
+    Acc accA, accB;
+    u32x4 res_r[SPS][4];  // residual of the group in flight: fp32 [j][a] = 4 floats; 16-bit [j][h] = 8 elements, h < 2
+
+    // asm loads of slice group GRP's residual of row tile pmt (every lane loads: out-of-range lanes read the zero page)
+    auto load_group = [&](auto GRP, int pmt) {
 #pragma unroll
-            for (int a = 0; a < NI; ++a) {
-                const int n = nb + ch_of(a);
-                const float* src = n < p.N_g ? p.bias + n : (const float*)p.zero_page;
-                bias_r[a] = *(const float4*)src;
-            }
-        }
-        if (p.res_mode == RES_SAME) {
+        for (int j = 0; j < SPS; ++j) {
+            const int m = pmt * BM + wm * TM + (decltype(GRP)::value * SPS + j) * 16 + lr;
+            if (f32o) {
 #pragma unroll
-            for (int b = 0; b < MI; ++b) {
-                const int m = mt * BM + wm * TM + b * 16 + lr;
-                if (f32o) {
+                for (int a = 0; a < NI; ++a) {
+                    const int n = nb + ch_of(a);
+                    const float* src = (m < p.M && n < p.N_g) ? (const float*)p.res + (size_t)m * p.ldr + n : (const float*)p.zero_page;
+                    gload16(res_r[j][a], src);
+                }
+            } else {
 #pragma unroll
-                    for (int a = 0; a < NI; ++a) {
-                        const int n = nb + ch_of(a);
-                        const float* src = (m < p.M && n < p.N_g) ? (const float*)p.res + (size_t)m * p.ldr + n : (const float*)p.zero_page;
-                        res_r[b][a] = *(const uint4*)src;
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int n = nb + 32 * j + 8 * g;
-                        const T* src = (m < p.M && n < p.N_g) ? (const T*)p.res + (size_t)m * p.ldr + n : (const T*)p.zero_page;
-                        res_r[b][j] = *(const uint4*)src;
-                    }
+                for (int h = 0; h < 2; ++h) {
+                    const int n = nb + 32 * h + 8 * g;
+                    const T* src = (m < p.M && n < p.N_g) ? (const T*)p.res + (size_t)m * p.ldr + n : (const T*)p.zero_page;
+                    gload16(res_r[j][h], src);
                 }
             }
         }
     };
-    // Exactly E32 / E16 store instructions per wave: out-of-range lanes write to the dump page instead of being skipped.
-    auto epilogue = [&](int tile) {
-        const int mt = tile / ntiles, nt = tile - mt * ntiles;
-        const int nb = nt * BN + wn * TN;
+    auto bind_group = [&]() {
 #pragma unroll
-        for (int b = 0; b < MI; ++b) {
-            const int m = mt * BM + wm * TM + b * 16 + lr;
-            float v[NI][4];
-#pragma unroll
-            for (int a = 0; a < NI; ++a) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[a][r] = acc[a][b][r];
-                acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (p.bias) {
-                    v[a][0] += bias_r[a].x; v[a][1] += bias_r[a].y; v[a][2] += bias_r[a].z; v[a][3] += bias_r[a].w;
-                }
-                if (p.res_post) activate(v[a]);
+        for (int j = 0; j < SPS; ++j) {
+            bind16(res_r[j][0]);
+            bind16(res_r[j][1]);
+            if (f32o) {
+                bind16(res_r[j][2]);
+                bind16(res_r[j][3]);
             }
-            if (p.res_mode == RES_SAME) {
-                if (f32o) {
+        }
+    };
+    // bias / activation / residual / store of slice group GRP of the parked tile (accumulators pnd, row tile pmt).  Exactly S32 / S16
+    // store instructions per wave: out-of-range lanes write to the dump page instead of being skipped.
+    auto run_group = [&](auto GRP, Acc& pnd, int pmt) {
+        // one accumulator fragment: bias, activation and (fp32) residual; chunks are fenced with sched_barrier so that the scheduler
+        // does not interleave all of a group's GELU polynomials (that costs more registers than the kernel has)
+        auto frag = [&](float (&v)[4], const f32x4& c, int a) {
+            const float4 bv = *(const float4*)(bias_s + wn * TN + ch_of(a));
+            v[0] = c[0] + bv.x; v[1] = c[1] + bv.y; v[2] = c[2] + bv.z; v[3] = c[3] + bv.w;
+            if (p.res_post) activate(v);
+        };
 #pragma unroll
-                    for (int a = 0; a < NI; ++a) {
-                        const uint4 u = res_r[b][a];
-                        v[a][0] += __uint_as_float(u.x); v[a][1] += __uint_as_float(u.y);
-                        v[a][2] += __uint_as_float(u.z); v[a][3] += __uint_as_float(u.w);
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        union { uint4 u; T h[8]; } rr;
-                        rr.u = res_r[b][j];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            v[2 * j][r] += to_f32<T>(rr.h[r]);
-                            v[2 * j + 1][r] += to_f32<T>(rr.h[4 + r]);
-                        }
-                    }
-                }
-            }
-            if (!p.res_post) {
-#pragma unroll
-                for (int a = 0; a < NI; ++a) activate(v[a]);
-            }
+        for (int j = 0; j < SPS; ++j) {
+            constexpr int q0 = decltype(GRP)::value * SPS;
+            const int m = pmt * BM + wm * TM + (q0 + j) * 16 + lr;
             const size_t row_off = (size_t)m * p.ldo + p.out_coff + nb;
             if (f32o) {
 #pragma unroll
                 for (int a = 0; a < NI; ++a) {
+                    float v[4];
+                    frag(v, pnd[a][q0 + j], a);
+                    if (has_res) {
+                        const u32x4 u = res_r[j][a];
+                        v[0] += __uint_as_float(u.x); v[1] += __uint_as_float(u.y);
+                        v[2] += __uint_as_float(u.z); v[3] += __uint_as_float(u.w);
+                    }
+                    if (!p.res_post) activate(v);
                     const int c = ch_of(a);
                     float* o = (m < p.M && nb + c < p.N_g) ? (float*)p.out + row_off + c : (float*)p.dump_page + lane * 4;
-                    *(float4*)o = make_float4(v[a][0], v[a][1], v[a][2], v[a][3]);
+                    *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int c = 32 * j + 8 * g;
-                    union { T h[8]; uint4 u; } pk;
+                for (int h = 0; h < 2; ++h) {
+                    float v0[4], v1[4];
+                    frag(v0, pnd[2 * h][q0 + j], 2 * h);
+                    frag(v1, pnd[2 * h + 1][q0 + j], 2 * h + 1);
+                    if (has_res) {
+                        union { u32x4 u; T e[8]; } rr;
+                        rr.u = res_r[j][h];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            v0[r] += to_f32<T>(rr.e[r]);
+                            v1[r] += to_f32<T>(rr.e[4 + r]);
+                        }
+                    }
+                    if (!p.res_post) {
+                        activate(v0);
+                        activate(v1);
+                    }
+                    const int c = 32 * h + 8 * g;
+                    union { T e[8]; uint4 u; } pk;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        pk.h[r] = from_f32<T>(v[2 * j][r]);
-                        pk.h[4 + r] = from_f32<T>(v[2 * j + 1][r]);
+                        pk.e[r] = from_f32<T>(v0[r]);
+                        pk.e[4 + r] = from_f32<T>(v1[r]);
                     }
                     T* o = (m < p.M && nb + c < p.N_g) ? (T*)p.out + row_off + c : (T*)p.dump_page + lane * 8;
                     *(uint4*)o = pk.u;
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
     };
 
-    // ---- persistent flat loop over (tile, k-step)
-    int c_tile = i_tile, c_ks = 0;  // compute cursor
-    if (c_tile >= total) return;
-    const int my_tiles = (total - c_tile + Gd - 1) / Gd;
+    // ---- persistent loop over (row tile, k-step)
+    const int my_tiles = (mtiles - mt0 + Gm - 1) / Gm;  // >= 1: Gm <= mtiles
     const int nsteps = my_tiles * nk;
-    setup_issue(i_tile);
-    issue_stage(0);
-    if (nsteps > 1) issue_stage(1);
-    bool after_epi = false;
+    int s = 0;                 // flat step counter: stage s lives in ring slot s % NSTAGE
+    bool stored = false;       // the previous step issued a slice group's stores
     long long tk[4] = {0, 0, 0, 0}, t0 = 0;
     auto tick = [&](int k) {
         if constexpr (PROF) {
@@ -254,25 +268,24 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const ConvParams p) {
             t0 = t;
         }
     };
-    if constexpr (PROF) t0 = clock64();
-    for (int s = 0; s < nsteps; ++s) {
-        // Wait until stage s has landed.  N = the VMEM ops issued after stage s's DMAs that may still be outstanding: stage s+1's DMAs
-        // and, right after an epilogue, its stores (the epilogue's loads were consumed, hence complete).
-        const bool younger = s + 1 < nsteps;
-        if (younger) {
-            if (!after_epi) wait_vm_barrier<G>();
-            else if (f32o) wait_vm_barrier<G + E32>();
-            else wait_vm_barrier<G + E16>();
+    // One K-step: MFMAs of the current tile into acc; when GRP >= 0 and a tile is parked, also slice group GRP of that tile.
+    auto step = [&](Acc& acc, Acc& pnd, auto GRP, bool parked, int pmt) {
+        constexpr int grp = decltype(GRP)::value;
+        // Wait until stage s has landed.  N = VMEM ops issued after stage s's DMAs that may still be outstanding: stage s+1's DMAs and
+        // the previous step's stores (its residual loads were consumed, hence complete; VMEM ops retire in issue order).
+        if (s + 1 < nsteps) {
+            if (!stored) wait_vm_barrier<G>(); else wait_vm_barrier<G + SG>();
         } else {
-            if (!after_epi) wait_vm_barrier<0>();
-            else if (f32o) wait_vm_barrier<E32>();
-            else wait_vm_barrier<E16>();
+            if (!stored) wait_vm_barrier<0>(); else wait_vm_barrier<SG>();
         }
-        after_epi = false;
         tick(0);
-        if (s + 2 < nsteps) issue_stage((s + 2) % NSTAGE);
-        const bool last_k = c_ks + 1 == nk;
-        if (last_k) prefetch_epi(c_tile);
+        bool run = false;
+        if constexpr (grp >= 0) {
+            run = parked;
+            if (run && has_res) load_group(GRP, pmt);
+        }
+        const bool dma = s + 2 < nsteps;
+        if (dma) issue_stage((s + 2) % NSTAGE);
         tick(1);
         const char* As = smem + (s % NSTAGE) * STAGE;
         const char* Bs = As + BM * 128;
@@ -288,18 +301,70 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const ConvParams p) {
             for (int a = 0; a < NI; ++a)
 #pragma unroll
                 for (int b = 0; b < MI; ++b) Mma<T>::half(wf[a], xf[b], acc[a][b]);
+            // with an fp32 residual slice in flight the second half's fragments must not be hoisted over the first half's MFMAs:
+            // the kernel sits at the 256-VGPR limit (the other wave of the SIMD covers the exposed LDS latency)
+            if constexpr (F32O && MI >= 4) __builtin_amdgcn_sched_barrier(0);
         }
         tick(2);
-        if (last_k) {
-            epilogue(c_tile);
-            after_epi = true;
-            c_ks = 0;
-            c_tile += Gd;
-            tick(3);
-        } else {
-            ++c_ks;
+        if constexpr (grp >= 0) {
+            if (run) {
+                if (has_res) {  // the group's loads are older than this step's DMAs only
+                    if (dma) wait_vm_only<G>(); else wait_vm_only<0>();
+                    bind_group();
+                }
+                run_group(GRP, pnd, pmt);
+            }
         }
+        stored = run;
+        ++s;
+        tick(3);
+    };
+    // One tile into acc; the parked tile's NGRP slice groups ride on its first NGRP K-steps (NGRP <= nk by the host contract).
+    auto tile = [&](Acc& acc, Acc& pnd, bool parked, int pmt) {
+#pragma unroll
+        for (int a = 0; a < NI; ++a)
+#pragma unroll
+            for (int b = 0; b < MI; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (NGRP >= 1) step(acc, pnd, IC<0>{}, parked, pmt);
+        if constexpr (NGRP >= 2) step(acc, pnd, IC<1>{}, parked, pmt);
+        if constexpr (NGRP >= 3) step(acc, pnd, IC<2>{}, parked, pmt);
+        if constexpr (NGRP >= 4) step(acc, pnd, IC<3>{}, parked, pmt);
+        static_assert(NGRP <= 4, "peel more steps");
+        for (int ks = NGRP; ks < nk; ++ks) step(acc, pnd, IC<-1>{}, false, pmt);
+    };
+    auto drain = [&](Acc& pnd, int pmt) {  // the last tile's epilogue (no DMA is in flight any more)
+        auto one = [&](auto GRP) {
+            if (has_res) {
+                load_group(GRP, pmt);
+                wait_vm_only<0>();
+                bind_group();
+            }
+            run_group(GRP, pnd, pmt);
+        };
+        if constexpr (NGRP >= 1) one(IC<0>{});
+        if constexpr (NGRP >= 2) one(IC<1>{});
+        if constexpr (NGRP >= 3) one(IC<2>{});
+        if constexpr (NGRP >= 4) one(IC<3>{});
+    };
+
+    setup_issue(i_mt);
+    issue_stage(0);
+    if (nsteps > 1) issue_stage(1);
+    if constexpr (PROF) t0 = clock64();
+    int mt = mt0;
+    bool parked = false;  // a finished tile sits in the other accumulator set
+    for (int t = 0; t < my_tiles; t += 2) {
+        tile(accA, accB, parked, mt - Gm);
+        if (t + 1 == my_tiles) {
+            drain(accA, mt);
+            break;
+        }
+        tile(accB, accA, true, mt);
+        mt += 2 * Gm;
+        parked = true;
+        if (t + 2 >= my_tiles) drain(accB, mt - Gm);
     }
+    tick(3);
     if constexpr (PROF) {
         if (lane == 0)
             for (int k = 0; k < 4; ++k) atomicAdd((unsigned long long*)p.out2 + k, (unsigned long long)tk[k]);
