@@ -146,6 +146,12 @@ int ocrvi_test_deform_conv(int device, int dtype, const float* x, const float* o
 int ocrvi_test_conv(int device, int dtype, const float* x, const float* weight_host, const float* bias_host,
                     int N, int C, int H, int W, int Co, int ksize, int sh, int sw, int groups, int act, float* out,
                     int iters, float* avg_ms);
+/* Linear / 1x1 convolution as a plain GEMM with the fused epilogue of the hot path: out[M][N] = act(a[M][K] . weight[N][K]^T + bias
+ * (+ res)) (res_post = 0) or act(...) + res (res_post = 1); a, res and out are float32 DEVICE buffers (converted to/from `dtype`
+ * around the call; the residual is kept in fp32 when out_f32 is set, as the recogniser's residual stream is), weight/bias HOST.  Takes
+ * the persistent LDS-DMA ring GEMM whenever the shape is eligible (svtrv2.py:51-61,80-86 Linears; resnet Bottleneck 1x1 convs). */
+int ocrvi_test_gemm(int device, int dtype, const float* a, const float* weight_host, const float* bias_host, const float* res, int M,
+                    int K, int N, int act, int res_post, int out_f32, float* out, int iters, float* avg_ms);
 /* Multi-head self-attention on a packed qkv tensor [B, N, 3*heads*32] float32 (layout of
  * qkv.reshape(B,N,3,heads,32), svtrv2.py:80) -> out [B, N, heads*32] float32 (svtrv2.py:82-85). */
 int ocrvi_test_attention(int device, int dtype, const float* qkv, int B, int N, int heads, float* out, int iters,

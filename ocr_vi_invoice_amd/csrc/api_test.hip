@@ -142,6 +142,44 @@ extern "C" int ocrvi_test_conv(int device, int dtype, const float* x, const floa
     return OCRVI_OK;
 }
 
+extern "C" int ocrvi_test_gemm(int device, int dtype, const float* a, const float* weight_host, const float* bias_host, const float* res, int M,
+                               int K, int N, int act, int res_post, int out_f32, float* out, int iters, float* avg_ms) {
+    OCRVI_CHECK(a && weight_host && out && M > 0 && K > 0 && N > 0, OCRVI_EINVAL, "test_gemm: bad argument");
+    OCRVI_HIP(hipSetDevice(device));
+    Scratch sc;
+    OCRVI_TRY(sc.init());
+    const bool f32o = out_f32 || dtype == OCRVI_F32;
+    DeviceStore st;
+    ConvLayer L;
+    PackedConv pc = pack_conv(weight_host, bias_host, N, K, 1, 1, 1, AM_CONV1, dtype);
+    OCRVI_TRY(upload_packed(st, pc, AM_CONV1, &L));
+    void *an = nullptr, *yn = nullptr, *rn = nullptr;
+    OCRVI_TRY(sc.alloc((size_t)M * K * dtype_size(dtype), &an));
+    OCRVI_TRY(sc.alloc((size_t)M * N * (f32o ? 4 : dtype_size(dtype)), &yn));
+    OCRVI_TRY(k_cast_from_f32(dtype, a, an, (size_t)M * K, sc.s));
+    Runner r(dtype, sc.s, (void*)256, 0);
+    Tensor tx; tx.p = an; tx.n = 1; tx.h = 1; tx.w = M; tx.c = K;
+    Tensor ty; ty.p = yn; ty.n = 1; ty.h = 1; ty.w = M; ty.c = N; ty.f32 = f32o;
+    Tensor tr = ty;
+    ConvOpts o;
+    o.act = act;
+    if (res) {  // the residual has the output's element type
+        if (f32o) {
+            rn = (void*)res;
+        } else {
+            OCRVI_TRY(sc.alloc((size_t)M * N * dtype_size(dtype), &rn));
+            OCRVI_TRY(k_cast_from_f32(dtype, res, rn, (size_t)M * N, sc.s));
+        }
+        tr.p = rn;
+        o.res = &tr; o.res_mode = RES_SAME; o.res_post = res_post;
+    }
+    OCRVI_TRY(timed(sc, iters, avg_ms, [&]() { return conv(r, L, tx, ty, o); }));
+    if (f32o) OCRVI_HIP(hipMemcpyAsync(out, yn, (size_t)M * N * 4, hipMemcpyDeviceToDevice, sc.s));
+    else OCRVI_TRY(k_nhwc_to_nchw_f32(dtype, yn, out, 1, 1, M * N, 1, 1, 0, sc.s));
+    OCRVI_HIP(hipStreamSynchronize(sc.s));
+    return OCRVI_OK;
+}
+
 extern "C" int ocrvi_test_attention(int device, int dtype, const float* qkv, int B, int N, int heads, float* out, int iters, float* avg_ms) {
     OCRVI_CHECK(qkv && out && B > 0 && N > 0 && heads > 0, OCRVI_EINVAL, "test_attention: bad argument");
     OCRVI_HIP(hipSetDevice(device));

@@ -99,6 +99,53 @@ def test_ring_gemm_kernel(case, dt):
     assert torch.equal(out, out2)     # the ring has no data race: repeated launches are bit-identical
 
 
+GEMM_CASES = [
+    # M, K, N, act (0 none, 1 ReLU, 2 GELU), residual, res_post, out_f32      -- all take the ring GEMM with its deferred epilogue
+    (70000, 256, 256, 1, True, 0, 0),      # Bottleneck conv3: relu(bn(conv) + identity); 256-row tiles, several per workgroup, ragged M
+    (66000, 64, 256, 1, True, 0, 0),       # layer1 conv3: one K-step per tile (128-row tiles, the ring crosses a tile every step)
+    (33000, 128, 512, 1, True, 0, 0),      # two K-steps per tile
+    (40000, 384, 1536, 2, False, 0, 0),    # fc1 + GELU, 12 column tiles
+    (40000, 1536, 384, 0, True, 0, 1),     # fc2 + fp32 residual stream (fp32 output), 24 K-steps
+    (50000, 256, 256, 0, True, 0, 1),      # proj + fp32 residual, four K-steps = exactly the four slice groups
+    (3000, 384, 232, 0, False, 0, 1),      # CTC head: N not a tile multiple, fp32 logits, short M
+    (45000, 512, 128, 2, True, 1, 0),      # activation before the residual add (res_post)
+    (255, 256, 128, 0, True, 0, 0),        # a single partial tile
+]
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("case", GEMM_CASES)
+def test_ring_gemm_epilogues(case, dt):
+    """out = act(a W^T + b (+ res)) or act(a W^T + b) + res through ocrvi_test_gemm against torch fp64->fp32; twice, bit-identical."""
+    M, K, N, act, with_res, res_post, out_f32 = case
+    L = _lib()
+    lib = L.load()
+    g = torch.Generator().manual_seed(M + K + N)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / np.sqrt(K)
+    b = torch.randn(N, generator=g) * 0.2
+    res = torch.randn(M, N, generator=g) if with_res else None
+    y = a.double() @ w.double().t() + b.double()
+    fact = {0: lambda t: t, 1: F.relu, 2: F.gelu}[act]
+    if res is not None and not res_post:
+        y = y + res.double()
+    y = fact(y)
+    if res is not None and res_post:
+        y = y + res.double()
+    ref = y.float()
+    ad, rd = a.cuda(), (res.cuda() if res is not None else None)
+    wh, bh = np.ascontiguousarray(w.numpy()), np.ascontiguousarray(b.numpy())
+    outs = []
+    for _ in range(2):
+        out = torch.empty((M, N), device="cuda")
+        ms = C.c_float(0)
+        L.check(lib.ocrvi_test_gemm(0, DT[dt], ad.data_ptr(), wh.ctypes.data, bh.ctypes.data, rd.data_ptr() if rd is not None else None,
+                                    M, K, N, act, res_post, out_f32, out.data_ptr(), 0, C.byref(ms)))
+        outs.append(out.cpu())
+    assert _rel_err(outs[0], ref) < TOL[dt], _rel_err(outs[0], ref)
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("stride", [1, 2])
 @pytest.mark.parametrize("C_", [128, 256])

@@ -1,0 +1,24 @@
+"""The ring GEMM (csrc/gemm_ring.h) synchronises its LDS-DMA ring and its inline-asm residual loads with hand-counted
+`s_waitcnt vmcnt(N)`.  That protocol holds only if the compiler adds no vector-memory operation of its own (spills) and no vmcnt
+wait of its own inside the pipeline, and leaves the asm loads' destination registers alone until the counted wait.  A run that passes
+says nothing about this (a DMA that happens to land early hides a missing wait), so the generated ISA is checked instead.
+Cross-compiles for gfx950; no GPU needed."""
+import os
+import shutil
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+
+
+@pytest.mark.skipif(not shutil.which("/opt/rocm/bin/hipcc"), reason="hipcc not available")
+def test_ring_gemm_isa_keeps_the_vmcnt_protocol_bf16():
+    import check_ring_isa
+    rep = check_ring_isa.check("conv_bf16.hip")
+    assert len(rep) >= 4                                   # {256, 128}-row tiles x {16-bit, fp32} output
+    for name, r in rep.items():
+        assert r["mfma"] > 0 and r["asm_loads"] > 0, name
+        assert r["scratch"] == 0, f"{name}: {r['scratch']} scratch instructions (register spills)"
+        assert not r["touches"], f"{name}: asm-loaded registers touched before the counted wait: {r['touches'][:3]}"
+        assert r["compiler_vmcnt_waits"] == ["s_waitcnt vmcnt(0)"], f"{name}: compiler vmcnt waits {r['compiler_vmcnt_waits']}"
