@@ -39,10 +39,10 @@ static int launch_tile(const ConvParams& p, hipStream_t stream) {
     return OCRVI_OK;
 }
 
-template <typename T, int BM, int NW, int SPS, bool F32O>
+template <typename T, int BM, int NW, int SPS, bool F32O, bool C3>
 static int launch_ring_f(const ConvParams& p, int grid, hipStream_t stream) {
     constexpr int smem = 3 * (BM + 128) * 128 + 512;  // ring + bias
-    auto kern = gemm_ring_kernel<T, BM, NW, SPS, F32O>;
+    auto kern = gemm_ring_kernel<T, BM, NW, SPS, F32O, C3>;
     static bool attr_done = false;
     if (!attr_done) {
         OCRVI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -51,7 +51,7 @@ static int launch_ring_f(const ConvParams& p, int grid, hipStream_t stream) {
 #ifdef OCRVI_RING_PROF_BUILD
     static const bool prof = getenv("OCRVI_RING_PROF") && atoi(getenv("OCRVI_RING_PROF"));
     if (prof) {  // development aid: cycle breakdown per phase, printed per launch (synchronises)
-        auto pk = gemm_ring_kernel<T, BM, NW, SPS, F32O, true>;
+        auto pk = gemm_ring_kernel<T, BM, NW, SPS, F32O, C3, true>;
         static unsigned long long* dbuf = nullptr;
         if (!dbuf) {
             OCRVI_HIP(hipMalloc((void**)&dbuf, 64));
@@ -77,14 +77,22 @@ static int launch_ring_f(const ConvParams& p, int grid, hipStream_t stream) {
 }
 
 template <typename T, int BM, int NW, int SPS>
-static int launch_ring_cfg(const ConvParams& p, int grid, hipStream_t stream) {
-    if constexpr (sizeof(T) == 4) return launch_ring_f<T, BM, NW, SPS, true>(p, grid, stream);
-    else if (p.out_f32) return launch_ring_f<T, BM, NW, SPS, true>(p, grid, stream);
-    else return launch_ring_f<T, BM, NW, SPS, false>(p, grid, stream);
+static int launch_ring_cfg(const ConvParams& p, int amode, int grid, hipStream_t stream) {
+    if constexpr (sizeof(T) == 4) {
+        return launch_ring_f<T, BM, NW, SPS, true, false>(p, grid, stream);
+    } else {
+        if (amode == AM_CONV3) {  // 3x3 mode: 16-bit output, 256-row tiles only (checked by gemm_ring_eligible)
+            if constexpr (BM == 256) return launch_ring_f<T, BM, NW, SPS, false, true>(p, grid, stream);
+            set_error("gemm_ring: 3x3 mode needs 256-row tiles");
+            return OCRVI_EINVAL;
+        }
+        if (p.out_f32) return launch_ring_f<T, BM, NW, SPS, true, false>(p, grid, stream);
+        return launch_ring_f<T, BM, NW, SPS, false, false>(p, grid, stream);
+    }
 }
 
 template <typename T>
-int launch_gemm_ring(const ConvParams& p_in, hipStream_t stream) {
+int launch_gemm_ring(const ConvParams& p_in, int amode, hipStream_t stream) {
     ConvParams p = p_in;
     OCRVI_TRY(ring_pages(&p.zero_page, &p.dump_page));
     static int n_cu = 0;
@@ -99,15 +107,15 @@ int launch_gemm_ring(const ConvParams& p_in, hipStream_t stream) {
     OCRVI_CHECK(ntiles >= 1 && ntiles <= n_cu && nk >= 1, OCRVI_EINVAL, "gemm_ring: Np=%d Kp=%d out of range", p.Np, p.Kp);
     // 256-row tiles (4 slice groups riding on the next tile's first 4 K-steps) when K is deep enough for that and M still gives every
     // CU work; otherwise 128-row tiles (one group)
-    const int bm = (nk >= 4 && cdiv(p.M, 256) * ntiles >= 192) ? 256 : 128;
+    const int bm = (nk >= 4 && (amode == AM_CONV3 || cdiv(p.M, 256) * ntiles >= 192)) ? 256 : 128;
     // one persistent workgroup per CU; a workgroup keeps its column tile, so the grid is Gm row-tile lanes x ntiles, with Gm chosen
     // for equal row-tile counts
     const int mtiles = cdiv(p.M, bm);
     int gm = std::min(mtiles, std::max(1, n_cu / ntiles));
     gm = cdiv(mtiles, cdiv(mtiles, gm));
     const int grid = gm * ntiles;
-    if (bm == 256) return launch_ring_cfg<T, 256, 8, 1>(p, grid, stream);
-    return launch_ring_cfg<T, 128, 8, 2>(p, grid, stream);
+    if (bm == 256) return launch_ring_cfg<T, 256, 8, 1>(p, amode, grid, stream);
+    return launch_ring_cfg<T, 128, 8, 2>(p, amode, grid, stream);  // MI = 2: one group
 }
 
 template <typename T, int AMODE>
@@ -179,7 +187,7 @@ int launch_conv(const ConvParams& p_in, int amode, hipStream_t stream) {
     OCRVI_CHECK(p.Kp >= ks * ks * p.Cin_g, OCRVI_EINVAL, "conv: Kp=%d < %d", p.Kp, ks * ks * p.Cin_g);
     OCRVI_CHECK((p.OH - 1) * p.SH - p.PH + ks - 1 < p.H + ks && (p.OW - 1) * p.SW - p.PW + ks - 1 < p.W + ks, OCRVI_EINVAL,
                 "conv: output %dx%d inconsistent with input %dx%d", p.OH, p.OW, p.H, p.W);
-    if (gemm_ring_eligible(p, amode, TypeInfo<T>::dtype)) return launch_gemm_ring<T>(p, stream);
+    if (gemm_ring_eligible(p, amode, TypeInfo<T>::dtype)) return launch_gemm_ring<T>(p, amode, stream);
     switch (amode) {
         case AM_CONV1: return launch_mode<T, AM_CONV1>(p, stream);
         case AM_CONV3: return launch_mode<T, AM_CONV3>(p, stream);

@@ -31,6 +31,14 @@ __device__ __forceinline__ void glds16(const char* sbase, unsigned voff, unsigne
                  : "v"(voff), "s"(sbase), "s"(lds_dst)
                  : "memory");
 }
+// same with a full per-lane 64-bit address (3x3 mode: border lanes are redirected to the zero page)
+__device__ __forceinline__ void glds16v(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
 __device__ __forceinline__ const char* uniform_ptr(const char* p) {  // tell the compiler the pointer is wave-uniform
     const unsigned long long v = (unsigned long long)p;
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
@@ -66,7 +74,7 @@ __device__ __forceinline__ void bind16(u32x4& r) { asm volatile("" : "+v"(r)); }
 // cycles spent in wait+barrier / issue / ds_read+MFMA / epilogue work and adds them into p.out2 (uint64[4]) at exit.
 template <int I> struct IC { static constexpr int value = I; };
 
-template <typename T, int BM, int NW, int SPS, bool F32O, bool PROF = false>
+template <typename T, int BM, int NW, int SPS, bool F32O, bool C3 = false, bool PROF = false>
 __global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams p) {
     constexpr int EPC = TypeInfo<T>::EPC, BKE = 8 * EPC;
     constexpr int BN = 128, WM = NW / 2, TM = BM / WM, TN = 64, MI = TM / 16, NI = 4;  // waves: WM along M x 2 along N
@@ -110,26 +118,68 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams 
     const int chunk = (lane & 7) ^ swz128(wave * 8 + prow);       // source chunk that must land in LDS chunk (lane & 7)
     const unsigned b_off = (unsigned)((wave * 8 + prow) * ldw_b + chunk * 16);
     const char* const b_tile = uniform_ptr((const char*)p.w + (size_t)(nt * BN) * ldw_b);
-    unsigned a_off[NA];
+    unsigned a_off[C3 ? 1 : NA];
     const char* a_tile = nullptr;                                 // row 0 of the tile at the issue cursor
+    // C3 (3x3, stride 1, pad 1, Cin % BKE == 0: K-step ks = tap (ks / cpb) x channel block (ks % cpb)): the A row of output pixel
+    // m at tap (r, s) is input pixel m + (r-1) W + (s-1) -- a uniform displacement -- or zeros outside the image: per piece one
+    // per-lane pointer to the centre pixel and a 9-bit mask of the taps that fall inside; invalid lanes read the zero page.
+    const char* a_ptr[C3 ? NA : 1];
+    unsigned a_mask[C3 ? NA : 1];
+    const int cpb = C3 ? p.Cin_g / BKE : 1;                       // channel blocks per tap
+    int i_tap = 0, i_cb = 0;
     int i_mt = mt0, i_ks = 0;                                     // issue cursor
     auto setup_issue = [&](int mt) {
-        a_tile = uniform_ptr(A + (size_t)mt * BM * lda_b);
-        const int last = p.M - 1 - mt * BM;                       // last valid row of this tile
+        if constexpr (C3) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) a_off[i] = (unsigned)(min((i * NW + wave) * 8 + prow, last) * lda_b + chunk * 16);
+            for (int i = 0; i < NA; ++i) {
+                const int m = mt * BM + (i * NW + wave) * 8 + prow;
+                const bool ok = m < p.M;
+                const int mm = ok ? m : 0;
+                const int t = fastdiv(mm, p.mg_ow), ow = mm - t * p.OW, oh = t - fastdiv(t, p.mg_oh) * p.OH;
+                a_ptr[i] = A + (size_t)mm * lda_b + chunk * 16;
+                unsigned mk = 0;
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        if (ok && (unsigned)(oh + r - 1) < (unsigned)p.H && (unsigned)(ow + c - 1) < (unsigned)p.W) mk |= 1u << (r * 3 + c);
+                a_mask[i] = mk;
+            }
+        } else {
+            a_tile = uniform_ptr(A + (size_t)mt * BM * lda_b);
+            const int last = p.M - 1 - mt * BM;                   // last valid row of this tile
+#pragma unroll
+            for (int i = 0; i < NA; ++i) a_off[i] = (unsigned)(min((i * NW + wave) * 8 + prow, last) * lda_b + chunk * 16);
+        }
     };
     auto issue_stage = [&](int slot) {  // DMA the stage at the issue cursor into ring slot `slot`, advance the cursor
         const unsigned base = lds0 + slot * STAGE;
-        const char* const ak = a_tile + (size_t)i_ks * 128;
         const char* const bk = b_tile + (size_t)i_ks * 128;
+        if constexpr (C3) {
+            const int r = i_tap / 3, c = i_tap - r * 3;
+            const long long delta = (long long)((r - 1) * p.W + (c - 1)) * lda_b + i_cb * 128;
+            const char* const zero = (const char*)p.zero_page + (lane & 7) * 16;
 #pragma unroll
-        for (int i = 0; i < NA; ++i) glds16(ak, a_off[i], __builtin_amdgcn_readfirstlane(base + (i * NW + wave) * 1024));
+            for (int i = 0; i < NA; ++i) {
+                const char* src = ((a_mask[i] >> i_tap) & 1u) ? a_ptr[i] + delta : zero;
+                glds16v(src, __builtin_amdgcn_readfirstlane(base + (i * NW + wave) * 1024));
+            }
+            if (++i_cb == cpb) {
+                i_cb = 0;
+                ++i_tap;
+            }
+        } else {
+            const char* const ak = a_tile + (size_t)i_ks * 128;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) glds16(ak, a_off[i], __builtin_amdgcn_readfirstlane(base + (i * NW + wave) * 1024));
+        }
 #pragma unroll
         for (int i = 0; i < NB; ++i)
             glds16(bk + (size_t)(i * NW * 8) * ldw_b, b_off, __builtin_amdgcn_readfirstlane(base + BM * 128 + (i * NW + wave) * 1024));
         if (++i_ks == nk) {
             i_ks = 0;
+            i_tap = 0;
+            i_cb = 0;
             i_mt += Gm;
             if (i_mt < mtiles) setup_issue(i_mt);
         }
@@ -371,7 +421,7 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams 
     }
 }
 
-template <typename T> int launch_gemm_ring(const ConvParams& p, hipStream_t stream);
+template <typename T> int launch_gemm_ring(const ConvParams& p, int amode, hipStream_t stream);
 // true when (p, amode) is a pure GEMM this kernel handles
 bool gemm_ring_eligible(const ConvParams& p, int amode, int dtype);
 int ring_pages(const void** zero_page, void** dump_page);  // device scratch pages (allocated once per process)

@@ -99,6 +99,35 @@ def test_ring_gemm_kernel(case, dt):
     assert torch.equal(out, out2)     # the ring has no data race: repeated launches are bit-identical
 
 
+RING_CONV3_CASES = [
+    # 3x3 / stride 1 / pad 1 convolutions large enough (M >= 16384, Cin % 64 == 0, Co >= 128) to take the ring kernel's 3x3 mode in the
+    # 16-bit modes (per-lane centre-pixel pointers + tap masks; border taps read the zero page): N, Cin, H, W, Co, act
+    (2, 64, 96, 100, 128, 1),     # ragged M (19200 = 75 tiles), every border
+    (1, 128, 131, 127, 256, 0),   # odd sizes: row / tile boundaries never align with image rows; two column tiles
+    (3, 256, 80, 72, 128, 1),     # K = 36 ring steps, three images (taps must not leak across image borders)
+]
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("case", RING_CONV3_CASES)
+def test_ring_conv3x3_kernel(case, dt):
+    # (tests/conftest.py lowers the dispatch threshold OCRVI_RING_CONV3_MIN_M from 2^18 rows to 16384 for the whole session)
+    N, Cin, H, W, Co, act = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Co, Cin, 3, 3, generator=g) / np.sqrt(9 * Cin)
+    b = torch.randn(Co, generator=g) * 0.1
+    ref = F.conv2d(x, w, b, 1, 1)
+    ref = F.relu(ref) if act == 1 else ref
+    out = run_conv(x, w, b, 3, 1, 1, 1, act, dt)
+    assert _rel_err(out, ref) < TOL[dt], _rel_err(out, ref)
+    # the borders specifically (where a wrong tap mask would show): first/last rows and columns of every image
+    edge = torch.zeros(H, W, dtype=torch.bool)
+    edge[0], edge[-1], edge[:, 0], edge[:, -1] = True, True, True, True
+    assert _rel_err(out[:, :, edge], ref[:, :, edge]) < TOL[dt]
+    assert torch.equal(out, run_conv(x, w, b, 3, 1, 1, 1, act, dt))
+
+
 GEMM_CASES = [
     # M, K, N, act (0 none, 1 ReLU, 2 GELU), residual, res_post, out_f32      -- all take the ring GEMM with its deferred epilogue
     (70000, 256, 256, 1, True, 0, 0),      # Bottleneck conv3: relu(bn(conv) + identity); 256-row tiles, several per workgroup, ragged M
