@@ -1,0 +1,109 @@
+// GEMM-shaped LDS-DMA stream without compute: per stage a workgroup DMAs an A piece set (32 KB: 256 rows x 128 B) and a W piece set
+// (16 KB: 128 rows x 128 B) into a 3-slot ring (ring GEMM protocol).  A: [M][K] bf16, K = 1536, each A tile shared by SHARE
+// consecutive workgroups (column tiles), streamed once overall; W: [384][K], L2-resident.  layout 0: row-major as stored today (a piece
+// = 8 rows x 128 B, rows 3072 B apart); layout 1: tile-major (a piece = 1 KiB contiguous).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+__device__ __forceinline__ void glds16(const char* sbase, unsigned voff, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vm_barrier() { asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory"); }
+
+template <int LAYOUT, int SHARE, int PF>
+__global__ __launch_bounds__(512, 1) void ring(const char* A, const char* W, int mtiles_per_wg, unsigned long long* sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int K = 1536, LDA = K * 2, NK = K / 64, STAGE = 48 * 1024;
+    const int wg = blockIdx.x, nt = wg % SHARE, lane_mt = wg / SHARE, Gm = gridDim.x / SHARE;
+    // per-lane offsets inside a tile (fixed), scalar bases per (tile, k-step)
+    unsigned a_off[4], w_off[2];
+    for (int i = 0; i < 4; ++i) {
+        const int piece = i * 8 + wave, row = piece * 8 + (lane >> 3);
+        a_off[i] = LAYOUT == 0 ? row * LDA + (lane & 7) * 16 : piece * (NK * 1024) + lane * 16;  // tile-major: [piece][k-step][1 KiB]
+    }
+    for (int i = 0; i < 2; ++i) {
+        const int piece = i * 8 + wave, row = piece * 8 + (lane >> 3);
+        w_off[i] = LAYOUT == 0 ? row * LDA + (lane & 7) * 16 : piece * (NK * 1024) + lane * 16;
+    }
+    const int nstage = mtiles_per_wg * NK;
+    auto issue = [&](int s) {
+        const int t = s / NK, ks = s - t * NK;
+        const int mt = lane_mt + t * Gm;
+        const char* ab = A + (size_t)mt * 256 * LDA + (LAYOUT == 0 ? ks * 128 : ks * 1024);
+        const char* wb = W + (size_t)nt * 128 * LDA + (LAYOUT == 0 ? ks * 128 : ks * 1024);
+        const unsigned base = lds0 + (s % 3) * STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(ab, a_off[i], __builtin_amdgcn_readfirstlane(base + (i * 8 + wave) * 1024));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16(wb, w_off[i], __builtin_amdgcn_readfirstlane(base + 32768 + (i * 8 + wave) * 1024));
+    };
+    // PF > 0: after each stage's DMAs every wave touches 32 of the 256 A lines of the stage PF steps further on with a plain
+    // 4-byte load (2 lanes per 128-B line), so that the line is in L2 by the time its DMA is issued.  The touch is issued AFTER the
+    // DMAs of its step: it is then younger than everything the next two waits need (vmcnt retires in order).
+    // The touch is an LDS-DMA of 4 bytes per lane into a per-wave scratch area behind the ring: it has no VGPR destination, so no
+    // register can be handed to something else while the load is in flight (a plain load whose result is never consumed is unsafe:
+    // the allocator frees or renames its destination immediately).
+    auto touch = [&](int s) {
+        if (PF == 0) return;
+        const int sp = s + PF;
+        const char* a = W + lane * 4;
+        if (sp < nstage) {
+            const int t = sp / NK, ks = sp - t * NK;
+            const int mt = lane_mt + t * Gm;
+            const int line = wave * 32 + (lane >> 1);
+            a = A + (size_t)mt * 256 * LDA + (LAYOUT == 0 ? (size_t)line * LDA + ks * 128 : (size_t)(line >> 3) * (NK * 1024) + ks * 1024 + (line & 7) * 128) +
+                (lane & 1) * 64;
+        }
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(a), "s"(__builtin_amdgcn_readfirstlane(lds0 + 3 * STAGE + wave * 256)) : "memory");
+    };
+    constexpr int E = PF ? 1 : 0;
+    issue(0); touch(0);
+    issue(1); touch(1);
+    for (int s = 0; s < nstage; ++s) {
+        if (s + 1 < nstage) wait_vm_barrier<6 + 2 * E>(); else wait_vm_barrier<0>();
+        if (s + 2 < nstage) { issue(s + 2); touch(s + 2); }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0 && smem[lane * 16] == 123) sink[0] = 1;
+}
+template <int LAYOUT, int SHARE, int PF> void run(const char* A, const char* W, unsigned long long* sink, hipEvent_t e0, hipEvent_t e1) {
+    auto k = ring<LAYOUT, SHARE, PF>;
+    const int smem = 3 * 48 * 1024 + 2048, grid = 240, tiles = 6;
+    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    float best = 1e9;
+    for (int it = 0; it < 4; ++it) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k, dim3(grid), dim3(512), smem, 0, A, W, tiles, sink);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (it && ms < best) best = ms;
+    }
+    const double bytes = (double)tiles * 24 * 48 * 1024 * grid;
+    printf("prefetch %d ahead, layout %d, A tile shared by %d workgroups: %6.1f GB/s per CU (%.2f us per 48-KB stage)  %5.2f TB/s chip; A from HBM %.2f TB/s\n", PF, LAYOUT, SHARE,
+           bytes / grid / best / 1e6, best * 1e3 / (tiles * 24), bytes / best / 1e9, (double)tiles * 24 * 32768 * grid / SHARE / best / 1e9);
+}
+int main() {
+    const size_t abytes = (size_t)240 * 6 * 256 * 3072;  // enough row tiles for SHARE = 1
+    char *A, *W;
+    CK(hipMalloc(&A, abytes)); CK(hipMemset(A, 1, abytes));
+    CK(hipMalloc(&W, 12 * 128 * 3072)); CK(hipMemset(W, 1, 12 * 128 * 3072));  // up to 12 column tiles
+    unsigned long long* sink; CK(hipMalloc(&sink, 8));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    run<0, 3, 0>(A, W, sink, e0, e1);
+    run<0, 3, 2>(A, W, sink, e0, e1);
+    run<0, 3, 3>(A, W, sink, e0, e1);
+    run<0, 3, 4>(A, W, sink, e0, e1);
+    run<0, 3, 6>(A, W, sink, e0, e1);
+    run<0, 3, 8>(A, W, sink, e0, e1);
+    run<0, 1, 0>(A, W, sink, e0, e1);
+    run<0, 1, 4>(A, W, sink, e0, e1);
+    run<0, 2, 0>(A, W, sink, e0, e1);
+    run<0, 2, 4>(A, W, sink, e0, e1);
+    run<0, 12, 0>(A, W, sink, e0, e1);
+    run<0, 12, 4>(A, W, sink, e0, e1);
+    return 0;
+}
