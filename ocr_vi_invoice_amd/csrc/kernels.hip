@@ -116,59 +116,95 @@ int k_maxpool3x3s2(int dtype, const void* x, void* y, int N, int H, int W, int C
     return OCRVI_OK;
 }
 
-// ------------------------------------------------------------------ LayerNorm: one wave per row
+// ------------------------------------------------------------------ LayerNorm
+// A row of D <= 128 elements takes half a wave (two rows per wave), longer rows a whole wave with up to 4 float4 per lane.  Every
+// wave walks rows with a grid stride and loads its next row before it reduces the current one, so a CU keeps two rows per wave in flight.
+template <int W> __device__ __forceinline__ float seg_sum(float v) {  // sum over aligned groups of W lanes
+#pragma unroll
+    for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+template <typename TI, typename TO, int LPR, int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x, TO* __restrict__ out, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, int rows, int D) {
+    constexpr int RPW = 64 / LPR;                       // rows per wave
+    const int lane = threadIdx.x & 63, sub = lane / LPR, l = lane % LPR;
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nwave = gridDim.x * (blockDim.x >> 6);
+    float g[NV][4], b[NV][4];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * LPR + l) * 4;
+        if (c < D) {
+            load4<float>(gamma + c, g[i]);
+            load4<float>(beta + c, b[i]);
+        }
+    }
+    float cur[NV][4], nxt[NV][4];
+    auto fetch = [&](int row, float (&v)[NV][4]) {
+        if (row >= rows) return;
+        const TI* xr = x + (size_t)row * D;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * LPR + l) * 4;
+            if (c < D) load4<TI>(xr + c, v[i]);
+        }
+    };
+    int row = wave * RPW + sub;
+    fetch(row, cur);
+    for (; row - sub < rows; row += nwave * RPW) {     // (wave-uniform trip count: the shuffles need every lane)
+        fetch(row + nwave * RPW, nxt);
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if ((i * LPR + l) * 4 < D) sum += cur[i][0] + cur[i][1] + cur[i][2] + cur[i][3];
+        const float mean = seg_sum<LPR>(sum) / (float)D;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if ((i * LPR + l) * 4 < D) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = cur[i][e] - mean; sq += d * d; }
+            }
+        const float rstd = rsqrtf(seg_sum<LPR>(sq) / (float)D + 1e-5f);
+        if (row < rows) {
+            TO* orow = out + (size_t)row * D;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = (i * LPR + l) * 4;
+                if (c < D) {
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (cur[i][e] - mean) * rstd * g[i][e] + b[i][e];
+                    store4<TO>(orow + c, o);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cur[i][e] = nxt[i][e];
+    }
+}
 template <typename TI, typename TO>
-__global__ void layernorm_kernel(const TI* __restrict__ x, TO* __restrict__ out, const float* __restrict__ gamma,
-                                 const float* __restrict__ beta, int rows, int D) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const TI* xr = x + (size_t)row * D;
-    constexpr int MAXV = 4;  // D <= 1024
-    float v[MAXV][4];
-    float sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int c = (i * 64 + lane) * 4;
-        if (c < D) {
-            load4<TI>(xr + c, v[i]);
-            sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
-        }
-    }
-    const float mean = wave_sum(sum) / (float)D;
-    float sq = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int c = (i * 64 + lane) * 4;
-        if (c < D) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; sq += d * d; }
-        }
-    }
-    const float rstd = rsqrtf(wave_sum(sq) / (float)D + 1e-5f);
-    TO* orow = out + (size_t)row * D;
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int c = (i * 64 + lane) * 4;
-        if (c < D) {
-            const float4 g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
-            float o[4] = {(v[i][0] - mean) * rstd * g.x + b.x, (v[i][1] - mean) * rstd * g.y + b.y,
-                          (v[i][2] - mean) * rstd * g.z + b.z, (v[i][3] - mean) * rstd * g.w + b.w};
-            store4<TO>(orow + c, o);
-        }
-    }
+static void launch_layernorm(const TI* x, TO* out, const float* gamma, const float* beta, int rows, int D, hipStream_t s) {
+    const int grid = std::min(cdiv(rows, 4), 256 * 8);  // 8 workgroups of 4 waves per CU, each wave walking rows
+    if (D <= 128) hipLaunchKernelGGL((layernorm_kernel<TI, TO, 32, 1>), dim3(std::min(cdiv(rows, 8), 256 * 8)), dim3(256), 0, s, x, out, gamma, beta, rows, D);
+    else if (D <= 256) hipLaunchKernelGGL((layernorm_kernel<TI, TO, 64, 1>), dim3(grid), dim3(256), 0, s, x, out, gamma, beta, rows, D);
+    else if (D <= 512) hipLaunchKernelGGL((layernorm_kernel<TI, TO, 64, 2>), dim3(grid), dim3(256), 0, s, x, out, gamma, beta, rows, D);
+    else hipLaunchKernelGGL((layernorm_kernel<TI, TO, 64, 4>), dim3(grid), dim3(256), 0, s, x, out, gamma, beta, rows, D);
+}
+template <typename T>
+static void layernorm_dt(const void* x, int x_f32, void* out, int out_f32, const float* gamma, const float* beta, int rows, int D, hipStream_t s) {
+    if (x_f32 && out_f32) launch_layernorm<float, float>((const float*)x, (float*)out, gamma, beta, rows, D, s);
+    else if (x_f32) launch_layernorm<float, T>((const float*)x, (T*)out, gamma, beta, rows, D, s);
+    else if (out_f32) launch_layernorm<T, float>((const T*)x, (float*)out, gamma, beta, rows, D, s);
+    else launch_layernorm<T, T>((const T*)x, (T*)out, gamma, beta, rows, D, s);
 }
 int k_layernorm(int dtype, const void* x, int x_f32, void* out, int out_f32, const float* gamma, const float* beta, int rows, int D,
                 hipStream_t s) {
     OCRVI_CHECK(x && out && gamma && beta && rows > 0 && D % 4 == 0 && D <= 1024, OCRVI_EINVAL, "layernorm: bad shape rows=%d D=%d", rows, D);
     ProfScope ps_("layernorm", 0.0, (double)rows*D*((x_f32?4:dtype_size(dtype))+(out_f32?4:dtype_size(dtype))), s);
-    const dim3 grid(cdiv(rows, 4)), block(256);
-    DISPATCH_DT(dtype, {
-        if (x_f32 && out_f32) hipLaunchKernelGGL((layernorm_kernel<float, float>), grid, block, 0, s, (const float*)x, (float*)out, gamma, beta, rows, D);
-        else if (x_f32) hipLaunchKernelGGL((layernorm_kernel<float, T>), grid, block, 0, s, (const float*)x, (T*)out, gamma, beta, rows, D);
-        else if (out_f32) hipLaunchKernelGGL((layernorm_kernel<T, float>), grid, block, 0, s, (const T*)x, (float*)out, gamma, beta, rows, D);
-        else hipLaunchKernelGGL((layernorm_kernel<T, T>), grid, block, 0, s, (const T*)x, (T*)out, gamma, beta, rows, D);
-    });
+    DISPATCH_DT(dtype, (layernorm_dt<T>(x, x_f32, out, out_f32, gamma, beta, rows, D, s)));
     OCRVI_HIP(hipGetLastError());
     return OCRVI_OK;
 }
