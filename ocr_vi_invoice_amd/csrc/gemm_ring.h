@@ -94,7 +94,7 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams 
     const int lr = lane & 15, g = lane >> 4;
     constexpr bool f32o = F32O;                                   // output (and residual) element type: fp32 or T
     static_assert(F32O || sizeof(T) == 2, "an fp32 GEMM has fp32 output");
-    const bool has_res = p.res_mode == RES_SAME;
+    const bool has_res = p.res_mode != RES_NONE;                  // RES_SAME, or RES_UP2: nearest 2x upsample of a half-resolution tensor
     const int swa = swz128(lr);                                   // A rows: b*16 + lr
     // B rows of MFMA block a: 16-bit output: 32*(a>>1) + 4*(a&1) + brow (channel permutation, see above); fp32 output: 16*a + lr
     const int brow = f32o ? lr : 8 * (lr >> 2) + (lr & 3);
@@ -212,18 +212,24 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams 
 #pragma unroll
         for (int j = 0; j < SPS; ++j) {
             const int m = pmt * BM + wm * TM + (decltype(GRP)::value * SPS + j) * 16 + lr;
+            size_t rrow = (size_t)m;  // residual row of output row m
+            if (p.res_mode == RES_UP2) {  // (neck.py:36-38) pixel (img, oh, ow) <- (img, oh / 2, ow / 2) of the half-resolution map
+                const int mm = m < p.M ? m : 0;
+                const int t = fastdiv(mm, p.mg_ow), ow = mm - t * p.OW, img = fastdiv(t, p.mg_oh), oh = t - img * p.OH;
+                rrow = ((size_t)img * (p.OH >> 1) + (oh >> 1)) * (p.OW >> 1) + (ow >> 1);
+            }
             if (f32o) {
 #pragma unroll
                 for (int a = 0; a < NI; ++a) {
                     const int n = nb + ch_of(a);
-                    const float* src = (m < p.M && n < p.N_g) ? (const float*)p.res + (size_t)m * p.ldr + n : (const float*)p.zero_page;
+                    const float* src = (m < p.M && n < p.N_g) ? (const float*)p.res + rrow * p.ldr + n : (const float*)p.zero_page;
                     gload16(res_r[j][a], src);
                 }
             } else {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int n = nb + 32 * h + 8 * g;
-                    const T* src = (m < p.M && n < p.N_g) ? (const T*)p.res + (size_t)m * p.ldr + n : (const T*)p.zero_page;
+                    const T* src = (m < p.M && n < p.N_g) ? (const T*)p.res + rrow * p.ldr + n : (const T*)p.zero_page;
                     gload16(res_r[j][h], src);
                 }
             }

@@ -190,15 +190,16 @@ bool gemm_ring_eligible(const ConvParams& p, int amode, int dtype) {
     static const bool on = !(getenv("OCRVI_GEMM_RING") && atoi(getenv("OCRVI_GEMM_RING")) == 0);
     static const bool on3 = !(getenv("OCRVI_RING_CONV3") && atoi(getenv("OCRVI_RING_CONV3")) == 0);
     if (!on || p.groups != 1 || p.store_mode != ST_NHWC) return false;
-    if (p.res_mode != RES_NONE && p.res_mode != RES_SAME) return false;
     const int esz = (int)dtype_size(dtype), bke = conv_bke(dtype);
     if (amode == AM_CONV3) {  // 3x3 / stride 1 / pad 1 on the ring: 16-bit types, whole channel blocks per tap, 256-row tiles
         if (!on3 || esz != 2 || p.out_f32 || p.KH != 3 || p.SH != 1 || p.SW != 1 || p.PH != 1 || p.PW != 1 || p.H != p.OH || p.W != p.OW) return false;
         // measured (profiles/r01_conv_variants.md): +5..9 % over conv_gemm at M >= 300 k rows, -12 % at 77 k (too few tiles per CU)
         static const int min_m = getenv("OCRVI_RING_CONV3_MIN_M") ? atoi(getenv("OCRVI_RING_CONV3_MIN_M")) : (1 << 18);
         if (p.Cin_g % bke != 0 || p.Kp != 9 * p.Cin_g || p.M < min_m) return false;
-    } else if (amode != AM_CONV1 || !p.identity_pix || p.Kp != p.Cin_g) {
-        return false;
+    } else {  // 1x1, stride 1, no padding: output pixel == input pixel (identity_pix, which launch_conv clears for RES_UP2 only)
+        if (amode != AM_CONV1 || p.Kp != p.Cin_g || p.SH != 1 || p.SW != 1 || p.PH != 0 || p.PW != 0 || p.H != p.OH || p.W != p.OW) return false;
+        if (!p.identity_pix && p.res_mode != RES_UP2) return false;
+        if (p.res_mode == RES_UP2 && ((p.OH | p.OW) & 1)) return false;
     }
     if (p.Cin_g % bke != 0 || p.N_g < 128 || p.N_g % 4 != 0 || p.Np % 128 != 0) return false;
     if (((size_t)p.cin_off * esz) % 16 != 0 || ((size_t)p.Cin * esz) % 16 != 0 || ((uintptr_t)p.x & 15) != 0) return false;
@@ -206,7 +207,7 @@ bool gemm_ring_eligible(const ConvParams& p, int amode, int dtype) {
     const bool of32 = p.out_f32 || esz == 4, rf32 = p.res_f32 || esz == 4;
     const int og = of32 ? 4 : 8;
     if (p.N_g % og != 0 || p.ldo % og != 0 || p.out_coff % og != 0 || ((uintptr_t)p.out & 15) != 0) return false;
-    if (p.res_mode == RES_SAME && (rf32 != of32 || p.ldr % og != 0 || ((uintptr_t)p.res & 15) != 0)) return false;
+    if (p.res_mode != RES_NONE && (rf32 != of32 || p.ldr % og != 0 || ((uintptr_t)p.res & 15) != 0)) return false;
     if (p.bias && ((uintptr_t)p.bias & 15) != 0) return false;
     return true;
 }
