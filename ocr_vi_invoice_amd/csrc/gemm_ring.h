@@ -145,6 +145,14 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams 
                         if (ok && (unsigned)(oh + r - 1) < (unsigned)p.H && (unsigned)(ow + c - 1) < (unsigned)p.W) mk |= 1u << (r * 3 + c);
                 a_mask[i] = mk;
             }
+        } else if (p.SH != 1 || p.SW != 1) {  // strided 1x1 (ResNet downsample): input pixel (img, oh*SH, ow*SW); offsets from the tensor base
+            a_tile = uniform_ptr(A);
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int m = min(mt * BM + (i * NW + wave) * 8 + prow, p.M - 1);
+                const int t = fastdiv(m, p.mg_ow), ow = m - t * p.OW, img = fastdiv(t, p.mg_oh), oh = t - img * p.OH;
+                a_off[i] = (unsigned)((img * p.H + oh * p.SH) * p.W + ow * p.SW) * (unsigned)lda_b + chunk * 16;
+            }
         } else {
             a_tile = uniform_ptr(A + (size_t)mt * BM * lda_b);
             const int last = p.M - 1 - mt * BM;                   // last valid row of this tile

@@ -197,9 +197,15 @@ bool gemm_ring_eligible(const ConvParams& p, int amode, int dtype) {
         static const int min_m = getenv("OCRVI_RING_CONV3_MIN_M") ? atoi(getenv("OCRVI_RING_CONV3_MIN_M")) : (1 << 18);
         if (p.Cin_g % bke != 0 || p.Kp != 9 * p.Cin_g || p.M < min_m) return false;
     } else {  // 1x1, stride 1, no padding: output pixel == input pixel (identity_pix, which launch_conv clears for RES_UP2 only)
-        if (amode != AM_CONV1 || p.Kp != p.Cin_g || p.SH != 1 || p.SW != 1 || p.PH != 0 || p.PW != 0 || p.H != p.OH || p.W != p.OW) return false;
-        if (!p.identity_pix && p.res_mode != RES_UP2) return false;
-        if (p.res_mode == RES_UP2 && ((p.OH | p.OW) & 1)) return false;
+        if (amode != AM_CONV1 || p.Kp != p.Cin_g || p.PH != 0 || p.PW != 0) return false;
+        const bool unit = p.SH == 1 && p.SW == 1 && p.H == p.OH && p.W == p.OW;
+        if (unit) {
+            if (!p.identity_pix && p.res_mode != RES_UP2) return false;
+            if (p.res_mode == RES_UP2 && ((p.OH | p.OW) & 1)) return false;
+        } else {  // strided 1x1 (downsample): per-lane 32-bit offsets from the tensor base
+            if (p.res_mode != RES_NONE || p.OH != (p.H - 1) / p.SH + 1 || p.OW != (p.W - 1) / p.SW + 1) return false;
+            if ((unsigned long long)p.n_img * p.H * p.W * p.Cin * esz >= (1ull << 32)) return false;
+        }
     }
     if (p.Cin_g % bke != 0 || p.N_g < 128 || p.N_g % 4 != 0 || p.Np % 128 != 0) return false;
     if (((size_t)p.cin_off * esz) % 16 != 0 || ((size_t)p.Cin * esz) % 16 != 0 || ((uintptr_t)p.x & 15) != 0) return false;

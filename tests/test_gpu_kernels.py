@@ -45,7 +45,9 @@ CONV_CASES = [
     # N, Cin, H, W, Co, ks, sh, sw, groups, act
     (2, 64, 12, 20, 64, 1, 1, 1, 1, 1),      # bottleneck conv1
     (2, 64, 12, 20, 256, 1, 1, 1, 1, 0),
-    (1, 256, 10, 14, 128, 1, 2, 2, 1, 0),    # downsample 1x1 stride 2
+    (1, 256, 10, 14, 128, 1, 2, 2, 1, 0),    # downsample 1x1 stride 2 (ring kernel, strided A rows)
+    (3, 128, 37, 45, 256, 1, 2, 2, 1, 1),    # the same with odd sizes, several images, several tiles
+    (2, 64, 50, 64, 128, 1, 2, 1, 1, 0),     # stride (2, 1)
     (2, 64, 13, 17, 64, 3, 1, 1, 1, 1),      # ragged M
     (1, 128, 16, 16, 128, 3, 2, 2, 1, 1),
     (2, 128, 12, 20, 128, 3, 1, 1, 4, 2),    # LocalMixing grouped conv + GELU
