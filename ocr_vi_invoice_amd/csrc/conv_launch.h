@@ -39,10 +39,10 @@ static int launch_tile(const ConvParams& p, hipStream_t stream) {
     return OCRVI_OK;
 }
 
-template <typename T, int BM, int NW, int SPS, bool F32O, bool C3>
+template <typename T, int BM, int NW, int SPS, bool F32O, bool C3, int BN = 128>
 static int launch_ring_f(const ConvParams& p, int grid, hipStream_t stream) {
-    constexpr int smem = 3 * (BM + 128) * 128 + 512;  // ring + bias
-    auto kern = gemm_ring_kernel<T, BM, NW, SPS, F32O, C3>;
+    constexpr int smem = 3 * (BM + BN) * 128 + 512;  // ring + bias
+    auto kern = gemm_ring_kernel<T, BM, NW, SPS, F32O, C3, BN>;
     static bool attr_done = false;
     if (!attr_done) {
         OCRVI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -51,7 +51,7 @@ static int launch_ring_f(const ConvParams& p, int grid, hipStream_t stream) {
 #ifdef OCRVI_RING_PROF_BUILD
     static const bool prof = getenv("OCRVI_RING_PROF") && atoi(getenv("OCRVI_RING_PROF"));
     if (prof) {  // development aid: cycle breakdown per phase, printed per launch (synchronises)
-        auto pk = gemm_ring_kernel<T, BM, NW, SPS, F32O, C3, true>;
+        auto pk = gemm_ring_kernel<T, BM, NW, SPS, F32O, C3, BN, true>;
         static unsigned long long* dbuf = nullptr;
         if (!dbuf) {
             OCRVI_HIP(hipMalloc((void**)&dbuf, 64));
@@ -103,17 +103,23 @@ int launch_gemm_ring(const ConvParams& p_in, int amode, hipStream_t stream) {
         OCRVI_HIP(hipGetDeviceProperties(&prop, dev));
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    const int ntiles = p.Np / 128, nk = p.Kp / (int)(128 / sizeof(T));
+    const int bn = p.Np % 128 == 0 ? 128 : 64;  // 64-channel layers: a 256x64 tile (16-bit types only, checked by gemm_ring_eligible)
+    const int ntiles = p.Np / bn, nk = p.Kp / (int)(128 / sizeof(T));
     OCRVI_CHECK(ntiles >= 1 && ntiles <= n_cu && nk >= 1, OCRVI_EINVAL, "gemm_ring: Np=%d Kp=%d out of range", p.Np, p.Kp);
     // 256-row tiles (4 slice groups riding on the next tile's first 4 K-steps) when K is deep enough for that and M still gives every
     // CU work; otherwise 128-row tiles (one group)
-    const int bm = (nk >= 4 && (amode == AM_CONV3 || cdiv(p.M, 256) * ntiles >= 192)) ? 256 : 128;
+    const int bm = bn == 64 ? 256 : ((nk >= 4 && (amode == AM_CONV3 || cdiv(p.M, 256) * ntiles >= 192)) ? 256 : 128);
     // one persistent workgroup per CU; a workgroup keeps its column tile, so the grid is Gm row-tile lanes x ntiles, with Gm chosen
     // for equal row-tile counts
     const int mtiles = cdiv(p.M, bm);
     int gm = std::min(mtiles, std::max(1, n_cu / ntiles));
     gm = cdiv(mtiles, cdiv(mtiles, gm));
     const int grid = gm * ntiles;
+    if constexpr (sizeof(T) == 2) {
+        if (bn == 64) {  // 8 waves along M (32 rows each: one slice group of two slices)
+            return launch_ring_f<T, 256, 8, 2, false, false, 64>(p, grid, stream);
+        }
+    }
     if (bm == 256) return launch_ring_cfg<T, 256, 8, 1>(p, amode, grid, stream);
     return launch_ring_cfg<T, 128, 8, 2>(p, amode, grid, stream);  // MI = 2: one group
 }

@@ -6,7 +6,7 @@
 // VGPRs) into a 3-stage ring that keeps streaming ACROSS tile boundaries: the next tile's first two K-steps are in flight while the
 // previous tile's epilogue runs.  One persistent workgroup per CU: a 256x128 tile on 4 waves (2 x 2, one per SIMD, 128x64 each: the
 // wave then owns the SIMD's whole 512-entry register file, which the parked accumulators of the deferred epilogue need), or a
-// 128x128 tile on 8 waves (4 x 2) for short M.
+// 128x128 tile on 8 waves (4 x 2) for short M, or a 256x64 tile (8 x 1) for 64-channel layers.
 //
 // Protocol per K-step s (slot = s % 3), every wave:
 //   s_waitcnt vmcnt(N)   own DMAs of stage s have landed        (N counts exactly the younger VMEM ops: stage s+1's DMAs and, right
@@ -74,10 +74,11 @@ __device__ __forceinline__ void bind16(u32x4& r) { asm volatile("" : "+v"(r)); }
 // cycles spent in wait+barrier / issue / ds_read+MFMA / epilogue work and adds them into p.out2 (uint64[4]) at exit.
 template <int I> struct IC { static constexpr int value = I; };
 
-template <typename T, int BM, int NW, int SPS, bool F32O, bool C3 = false, bool PROF = false>
+template <typename T, int BM, int NW, int SPS, bool F32O, bool C3 = false, int BN = 128, bool PROF = false>
 __global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams p) {
     constexpr int EPC = TypeInfo<T>::EPC, BKE = 8 * EPC;
-    constexpr int BN = 128, WM = NW / 2, TM = BM / WM, TN = 64, MI = TM / 16, NI = 4;  // waves: WM along M x 2 along N
+    static_assert(BN == 128 || BN == 64, "column tile");
+    constexpr int WN = BN / 64, WM = NW / WN, TM = BM / WM, TN = 64, MI = TM / 16, NI = 4;  // waves: WM along M x WN along N, 64 columns each
     constexpr int STAGE = (BM + BN) * 128, NSTAGE = 3;
     constexpr int NA = BM / 8 / NW, NB = BN / 8 / NW;  // 1-KiB DMA pieces per wave per stage (8 rows x 128 B each)
     constexpr int G = NA + NB;                 // VMEM ops per wave per stage
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams 
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int lr = lane & 15, g = lane >> 4;
     constexpr bool f32o = F32O;                                   // output (and residual) element type: fp32 or T
     static_assert(F32O || sizeof(T) == 2, "an fp32 GEMM has fp32 output");

@@ -195,7 +195,7 @@ bool gemm_ring_eligible(const ConvParams& p, int amode, int dtype) {
         if (!on3 || esz != 2 || p.out_f32 || p.KH != 3 || p.SH != 1 || p.SW != 1 || p.PH != 1 || p.PW != 1 || p.H != p.OH || p.W != p.OW) return false;
         // measured (profiles/r01_conv_variants.md): +5..9 % over conv_gemm at M >= 300 k rows, -12 % at 77 k (too few tiles per CU)
         static const int min_m = getenv("OCRVI_RING_CONV3_MIN_M") ? atoi(getenv("OCRVI_RING_CONV3_MIN_M")) : (1 << 18);
-        if (p.Cin_g % bke != 0 || p.Kp != 9 * p.Cin_g || p.M < min_m) return false;
+        if (p.Cin_g % bke != 0 || p.Kp != 9 * p.Cin_g || p.M < min_m || p.Np % 128 != 0) return false;  // (64-wide: conv_gemm is 6 % faster)
     } else {  // 1x1, stride 1, no padding: output pixel == input pixel (identity_pix, which launch_conv clears for RES_UP2 only)
         if (amode != AM_CONV1 || p.Kp != p.Cin_g || p.PH != 0 || p.PW != 0) return false;
         const bool unit = p.SH == 1 && p.SW == 1 && p.H == p.OH && p.W == p.OW;
@@ -207,7 +207,9 @@ bool gemm_ring_eligible(const ConvParams& p, int amode, int dtype) {
             if ((unsigned long long)p.n_img * p.H * p.W * p.Cin * esz >= (1ull << 32)) return false;
         }
     }
-    if (p.Cin_g % bke != 0 || p.N_g < 128 || p.N_g % 4 != 0 || p.Np % 128 != 0) return false;
+    if (p.Cin_g % bke != 0 || p.N_g % 4 != 0) return false;
+    if (p.Np % 128 != 0 && !(p.Np == 64 && p.N_g == 64 && esz == 2 && !p.out_f32)) return false;  // 128-wide column tiles, or one 64-wide
+    if (p.N_g < 64) return false;
     if (((size_t)p.cin_off * esz) % 16 != 0 || ((size_t)p.Cin * esz) % 16 != 0 || ((uintptr_t)p.x & 15) != 0) return false;
     // 16-byte epilogue accesses: 4 fp32 or 8 16-bit channels
     const bool of32 = p.out_f32 || esz == 4, rf32 = p.res_f32 || esz == 4;

@@ -107,6 +107,7 @@ RING_CONV3_CASES = [
     (2, 64, 96, 100, 128, 1),     # ragged M (19200 = 75 tiles), every border
     (1, 128, 131, 127, 256, 0),   # odd sizes: row / tile boundaries never align with image rows; two column tiles
     (3, 256, 80, 72, 128, 1),     # K = 36 ring steps, three images (taps must not leak across image borders)
+    (2, 64, 96, 100, 64, 1),      # 64 output channels (ResNet layer1 conv2): stays on conv_gemm, which is faster there
 ]
 
 
@@ -141,6 +142,8 @@ GEMM_CASES = [
     (3000, 384, 232, 0, False, 0, 1),      # CTC head: N not a tile multiple, fp32 logits, short M
     (45000, 512, 128, 2, True, 1, 0),      # activation before the residual add (res_post)
     (255, 256, 128, 0, True, 0, 0),        # a single partial tile
+    (50000, 256, 64, 1, False, 0, 0),      # 64 output channels: the 256x64 tile (ResNet layer1 conv1), 4 K-steps
+    (20000, 64, 64, 1, False, 0, 0),       # the same with a single K-step per tile
 ]
 
 
