@@ -8,6 +8,7 @@
 
 #include "conv_gemm.h"
 #include "gemm_ring.h"
+#include "gconv32.h"
 
 namespace ocrvi {
 
@@ -193,6 +194,9 @@ int launch_conv(const ConvParams& p_in, int amode, hipStream_t stream) {
     OCRVI_CHECK(p.Kp >= ks * ks * p.Cin_g, OCRVI_EINVAL, "conv: Kp=%d < %d", p.Kp, ks * ks * p.Cin_g);
     OCRVI_CHECK((p.OH - 1) * p.SH - p.PH + ks - 1 < p.H + ks && (p.OW - 1) * p.SW - p.PW + ks - 1 < p.W + ks, OCRVI_EINVAL,
                 "conv: output %dx%d inconsistent with input %dx%d", p.OH, p.OW, p.H, p.W);
+    if constexpr (sizeof(T) == 2) {
+        if (gconv32_eligible(p, amode, 2)) return launch_gconv32<T>(p, stream);
+    }
     if (gemm_ring_eligible(p, amode, TypeInfo<T>::dtype)) return launch_gemm_ring<T>(p, amode, stream);
     switch (amode) {
         case AM_CONV1: return launch_mode<T, AM_CONV1>(p, stream);

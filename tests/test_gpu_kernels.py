@@ -51,6 +51,8 @@ CONV_CASES = [
     (2, 64, 13, 17, 64, 3, 1, 1, 1, 1),      # ragged M
     (1, 128, 16, 16, 128, 3, 2, 2, 1, 1),
     (2, 128, 12, 20, 128, 3, 1, 1, 4, 2),    # LocalMixing grouped conv + GELU
+    (3, 256, 6, 80, 256, 3, 1, 1, 8, 2),     # the same at the stage-1 shape (direct halo-tile kernel in the 16-bit modes: 8 groups, full-width tile)
+    (1, 128, 7, 100, 128, 3, 1, 1, 4, 1),    # ragged: two column bands (80 + 20), two row bands (4 + 3)
     (2, 128, 12, 20, 256, 3, 2, 1, 1, 0),    # PatchMerging stride (2,1)
     (1, 128, 9, 11, 27, 3, 1, 1, 1, 0) ,     # narrow-N (offset-conv shaped, generic store path needs N%4: use 28)
     (3, 96, 1, 1, 232, 1, 1, 1, 1, 0),       # Linear-shaped, K=96 (padded K), N=232
