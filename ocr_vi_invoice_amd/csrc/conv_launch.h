@@ -15,27 +15,10 @@ namespace ocrvi {
 template <typename T, int AMODE, int BM, int BN, int WM, int WN>
 static int launch_tile(const ConvParams& p, hipStream_t stream) {
     constexpr int smem = (BM + BN) * 128;
-    static const int persist = getenv("OCRVI_CONV_PERSIST") ? atoi(getenv("OCRVI_CONV_PERSIST")) : 0;  // experiment knob
-    void (*kern)(const ConvParams) = persist == 2 ? conv_gemm_kernel<T, AMODE, BM, BN, WM, WN, 2> : conv_gemm_kernel<T, AMODE, BM, BN, WM, WN, 0>;
-    static const int tiles_per_wg = getenv("OCRVI_CONV_TPW") ? atoi(getenv("OCRVI_CONV_TPW")) : 4;
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        OCRVI_HIP(hipGetDevice(&dev));
-        OCRVI_HIP(hipGetDeviceProperties(&prop, dev));
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    // persistent grid: at most (resident workgroups per CU) x CUs, and balanced so every workgroup walks the same number of tiles
+    // one tile per workgroup (PERSIST = 0): the persistent variants of conv_gemm_kernel were measured and lose 10-35 % on every shape
+    // (profiles/r01_conv_variants.md); they are no longer instantiated
     const int total = cdiv(p.M, BM) * (p.Np / BN);
-    int grid_x = total;
-    if (persist == 2) {  // every workgroup walks `tiles_per_wg` tiles (fewer when the grid would not fill the chip)
-        const int gmin = n_cu * ConvOcc<AMODE, BM, BN>::value;
-        int tpw = tiles_per_wg;
-        while (tpw > 1 && cdiv(total, tpw) < gmin) --tpw;
-        grid_x = cdiv(total, tpw);
-    }
-    hipLaunchKernelGGL(kern, dim3(grid_x, p.groups), dim3(256), smem, stream, p);
+    hipLaunchKernelGGL((conv_gemm_kernel<T, AMODE, BM, BN, WM, WN, 0>), dim3(total, p.groups), dim3(256), smem, stream, p);
     OCRVI_HIP(hipGetLastError());
     return OCRVI_OK;
 }
