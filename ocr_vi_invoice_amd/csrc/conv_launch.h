@@ -92,7 +92,12 @@ int launch_gemm_ring(const ConvParams& p_in, int amode, hipStream_t stream) {
     OCRVI_CHECK(ntiles >= 1 && ntiles <= n_cu && nk >= 1, OCRVI_EINVAL, "gemm_ring: Np=%d Kp=%d out of range", p.Np, p.Kp);
     // 256-row tiles (4 slice groups riding on the next tile's first 4 K-steps) when K is deep enough for that and M still gives every
     // CU work; otherwise 128-row tiles (one group)
-    const int bm = bn == 64 ? 256 : ((nk >= 4 && (amode == AM_CONV3 || cdiv(p.M, 256) * ntiles >= 192)) ? 256 : 128);
+    static const bool mid = !(getenv("OCRVI_RING_MID") && atoi(getenv("OCRVI_RING_MID")) == 0);  // experiment knob
+    const bool big_m = amode == AM_CONV3 || cdiv(p.M, 256) * ntiles >= 192;
+    const bool f32o = sizeof(T) == 4 || p.out_f32;
+    // nk = 2..3 with a 16-bit output: 256-row tiles with two slice groups of two slices (the fp32-output build of that shape spills)
+    const bool mid256 = mid && nk >= 2 && nk < 4 && !f32o && big_m && amode == AM_CONV1;
+    const int bm = bn == 64 ? 256 : (((nk >= 4 && big_m) || mid256) ? 256 : 128);
     // one persistent workgroup per CU; a workgroup keeps its column tile, so the grid is Gm row-tile lanes x ntiles, with Gm chosen
     // for equal row-tile counts
     const int mtiles = cdiv(p.M, bm);
@@ -103,6 +108,9 @@ int launch_gemm_ring(const ConvParams& p_in, int amode, hipStream_t stream) {
         if (bn == 64) {  // 8 waves along M (32 rows each: one slice group of two slices)
             return launch_ring_f<T, 256, 8, 2, false, false, 64>(p, grid, stream);
         }
+    }
+    if constexpr (sizeof(T) == 2) {
+        if (bm == 256 && mid256) return launch_ring_f<T, 256, 8, 2, false, false>(p, grid, stream);
     }
     if (bm == 256) return launch_ring_cfg<T, 256, 8, 1>(p, amode, grid, stream);
     return launch_ring_cfg<T, 128, 8, 2>(p, amode, grid, stream);  // MI = 2: one group
