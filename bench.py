@@ -356,7 +356,7 @@ def main():
             res["kernel_time_ms_per_step"] = {k: round(v["ms"] / prof_steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
             mf = sum(v["flops"] for v in prof.values())
             res["model_mfma_tflops"] = round(mf / (tot / 1e3) / 1e12, 2)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only
             cb, cer = cpu_baseline(args, det_sd, rec_sd, images_u8[0], pipe.crops if args.workload != "det" else None, texts)
             res["cpu_baseline"] = cb
             if cer is not None:
