@@ -1,6 +1,7 @@
+"""Grouped 3x3 (LocalMixing) micro-benchmark: direct halo-tile kernel vs conv_gemm (OCRVI_GCONV32=0), with and without GELU."""
 import ctypes as C, os, sys
 import numpy as np, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from ocr_vi_invoice_amd import _lib
 lib = _lib.load()
 for name, N, Cc, H, W, Co, g, act in [("d128 gelu",256,128,12,80,128,4,2),("d128 none",256,128,12,80,128,4,0),("d256 gelu",256,256,6,80,256,8,2),("d256 none",256,256,6,80,256,8,0)]:
