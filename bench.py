@@ -356,6 +356,23 @@ def main():
             res["kernel_time_ms_per_step"] = {k: round(v["ms"] / prof_steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
             mf = sum(v["flops"] for v in prof.values())
             res["model_mfma_tflops"] = round(mf / (tot / 1e3) / 1e12, 2)
+        if world == 1 and args.workload == "e2e":
+            # SURVEY 8(f) row 1 (not in the timed region): the host DB post-processor on a detector-like map of one
+            # page (ground-truth line boxes rendered as blobs), through the C ABI, one core
+            try:
+                from ocr_vi_invoice_amd.pipeline import DBPostProcessor
+                pm = np.random.default_rng(0).uniform(0.0, 0.2, (args.height, args.width)).astype(np.float32)
+                for _, x, y, w, h in boxes[boxes[:, 0] == 0]:
+                    pm[y + 1:y + h - 1, x + 1:x + w - 1] = 0.9
+                pp = DBPostProcessor()
+                nb = len(pp(pm[None])[0])
+                t1 = time.perf_counter()
+                for _ in range(10):
+                    pp(pm[None])
+                res["db_postprocess_host"] = {"ms_per_page": round((time.perf_counter() - t1) / 10 * 1e3, 3), "boxes": nb, "cores": 1,
+                                              "in_timed_region": False}
+            except Exception as e:  # noqa: BLE001  (a reported extra, never fatal)
+                res["db_postprocess_host"] = {"error": str(e)[:120]}
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only
             cb, cer = cpu_baseline(args, det_sd, rec_sd, images_u8[0], pipe.crops if args.workload != "det" else None, texts)
             res["cpu_baseline"] = cb
