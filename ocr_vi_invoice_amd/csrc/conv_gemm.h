@@ -52,7 +52,6 @@ struct ConvParams {
     int identity_pix = 0;  // 1x1, stride 1, pad 0: input pixel index == m (no decomposition needed)
     int epi_lds = 0;       // stage the output tile through LDS and store whole rows (ST_NHWC only; set by launch_conv)
     int res_in_store = 0;  // fp32 out + fp32 residual, no activation: add the residual in the coalesced store phase
-    int dbg = 0;           // ablation switches for timing experiments only (results are wrong when set): 1 = no DCN blend, 2 = one corner
 };
 
 __device__ __forceinline__ int fastdiv(int n, unsigned long long mg) { return (int)(((unsigned long long)(unsigned)n * mg) >> 40); }
@@ -204,17 +203,13 @@ __global__ __launch_bounds__(256, (ConvOcc<AMODE, BM, BN>::value)) void conv_gem
             for (int i = 0; i < APASS; ++i) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    if (q == 0 || !(p.dbg & 2)) st.c[i][q] = *(const uint4*)(X + (size_t)dco[i][q] * p.Cin + cbase + c);
+                    st.c[i][q] = *(const uint4*)(X + (size_t)dco[i][q] * p.Cin + cbase + c);
             }
         }
     };
 
     auto commit = [&]() {
         if constexpr (AMODE == AM_DCN) {
-            if (p.dbg & 1) {
-#pragma unroll
-                for (int i = 0; i < APASS; ++i) st.a[i] = st.c[i][0];
-            } else
 #pragma unroll
             for (int i = 0; i < APASS; ++i) {
                 float acc[EPC], f[EPC];

@@ -142,7 +142,6 @@ int launch_conv(const ConvParams& p_in, int amode, hipStream_t stream) {
     constexpr int EPC = TypeInfo<T>::EPC, BKE = 8 * EPC;
     ConvParams p = p_in;
     OCRVI_CHECK(p.M > 0 && p.M < (1 << 23) && p.OW > 0 && p.OH > 0, OCRVI_EINVAL, "conv: M=%d outside (0, 2^23)", p.M);
-    p.dbg = getenv("OCRVI_CONV_DBG") ? atoi(getenv("OCRVI_CONV_DBG")) : 0;
     p.mg_ow = ((1ull << 40) / (unsigned long long)p.OW) + 1;
     p.mg_oh = ((1ull << 40) / (unsigned long long)p.OH) + 1;
     p.identity_pix = (amode == AM_CONV1 && p.SH == 1 && p.SW == 1 && p.PH == 0 && p.PW == 0 && p.H == p.OH && p.W == p.OW &&
