@@ -97,7 +97,8 @@ int launch_gemm_ring(const ConvParams& p_in, int amode, hipStream_t stream) {
     const bool f32o = sizeof(T) == 4 || p.out_f32;
     // nk = 2..3 with a 16-bit output: 256-row tiles with two slice groups of two slices (the fp32-output build of that shape spills)
     const bool mid256 = mid && nk >= 2 && nk < 4 && !f32o && big_m && amode == AM_CONV1;
-    const int bm = bn == 64 ? 256 : (((nk >= 4 && big_m) || mid256) ? 256 : 128);
+    // (fp32 GEMMs -- the parity mode -- stay on 128-row tiles: their 256-row build does not fit the register file without a spill)
+    const int bm = bn == 64 ? 256 : ((sizeof(T) == 2 && ((nk >= 4 && big_m) || mid256)) ? 256 : 128);
     // one persistent workgroup per CU; a workgroup keeps its column tile, so the grid is Gm row-tile lanes x ntiles, with Gm chosen
     // for equal row-tile counts
     const int mtiles = cdiv(p.M, bm);
@@ -112,7 +113,9 @@ int launch_gemm_ring(const ConvParams& p_in, int amode, hipStream_t stream) {
     if constexpr (sizeof(T) == 2) {
         if (bm == 256 && mid256) return launch_ring_f<T, 256, 8, 2, false, false>(p, grid, stream);
     }
-    if (bm == 256) return launch_ring_cfg<T, 256, 8, 1>(p, amode, grid, stream);
+    if constexpr (sizeof(T) == 2) {
+        if (bm == 256) return launch_ring_cfg<T, 256, 8, 1>(p, amode, grid, stream);
+    }
     return launch_ring_cfg<T, 128, 8, 2>(p, amode, grid, stream);  // MI = 2: one group
 }
 

@@ -13,10 +13,11 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
 
 
 @pytest.mark.skipif(not shutil.which("/opt/rocm/bin/hipcc"), reason="hipcc not available")
-def test_ring_gemm_isa_keeps_the_vmcnt_protocol_bf16():
+@pytest.mark.parametrize("src,nmin", [("conv_bf16.hip", 6), ("conv_f16.hip", 6), ("conv_f32.hip", 1)])
+def test_ring_gemm_isa_keeps_the_vmcnt_protocol(src, nmin):
     import check_ring_isa
-    rep = check_ring_isa.check("conv_bf16.hip")
-    assert len(rep) >= 4                                   # {256, 128}-row tiles x {16-bit, fp32} output
+    rep = check_ring_isa.check(src)
+    assert len(rep) >= nmin                                # 16-bit: {256, 128}-row tiles x {16-bit, fp32} output, 3x3 mode, 256x64; fp32: 128-row
     for name, r in rep.items():
         assert r["mfma"] > 0 and r["asm_loads"] > 0, name
         assert r["scratch"] == 0, f"{name}: {r['scratch']} scratch instructions (register spills)"
