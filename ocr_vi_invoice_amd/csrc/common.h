@@ -152,7 +152,7 @@ __device__ __forceinline__ float gelu_erf(float x) {
     q = fmaf(q, t, 0.5f * -0.284496736f);
     q = fmaf(q, t, 0.5f * 0.254829592f);
     const float h = q * t * __builtin_amdgcn_exp2f(x * x * (-0.5f * 1.44269504088896340736f));  // erfc(z) / 2
-    return x * (x >= 0.f ? 1.0f - h : h);
+    return fmaxf(x, 0.f) - ax * h;   // x (1 - h) for x >= 0, x h = -|x| h otherwise
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
