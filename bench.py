@@ -1,33 +1,42 @@
 #!/usr/bin/env python3
-"""Benchmark of the hot path on MI355X: end-to-end invoice images/s (detect -> crop -> recognise).
+"""Benchmark of the hot path on MI355X: end-to-end invoice images/s (detect -> post-process -> crop -> recognise).
 
-Contract: `python bench.py --gpus N --steps K --warmup W` (for N > 1 launched by torch.distributed.run, one rank per GPU).
-One step = one pass over one batch per rank: `--batch` synthetic 960x1280 invoices (uint8, resident in HBM) ->
-normalise -> DBNet++ forward (all five maps, chunks of `--det-chunk`) -> crop+resize+normalise of the ground-truth line
-boxes (`--lines` per invoice) -> SVTRv2-base forward in batches of `--rec-batch` -> greedy CTC on device -> ids to host ->
-strings.  Images shard across ranks with no data-path collective (weak scaling); RCCL is used once, to broadcast the
-packed weights from rank 0.
+Contract: `python bench.py --gpus N --steps K --warmup W`.  With N > 1 and no WORLD_SIZE in the environment this process starts the N
+ranks itself (`python -m torch.distributed.run --nproc-per-node N bench.py ...`, before anything touches the GPU) and relays rank 0's
+JSON line; when the driver has already launched the ranks (WORLD_SIZE set) it is simply rank RANK of them.
 
-With random (seeded) weights the probability map carries no text structure, so crop boxes come from the synthetic
-generator's ground truth (`boxes=synthetic-gt`); DB post-processing (contours/unclip) is a host
-stage listed as the next row in DESIGN.md and is NOT inside the timed region.
+One step (workload e2e = BASELINE.json configs[3]) = one pass over this rank's batch of `--batch` synthetic 960x1280 invoices that
+are resident in HBM as uint8:
+  det stream   per chunk of `--det-chunk` pages: normalise -> DBNet++ forward (all five maps) -> probability map -> pinned host memory
+  host         DB post-processing of every page (threshold, contours, polygon, score, unclip), boxes -> crop rectangles, on a pool of
+               host threads, pipelined one chunk behind the detector (src/pipeline/pipeline2.py:320-343 does this on the host too)
+  rec stream   rectangles -> device; crop + resize + normalise from the resident pages -> SVTRv2-base in batches of `--rec-batch` ->
+               greedy CTC on device -> ids to pinned host memory -> strings
+The recogniser therefore consumes exactly the boxes the post-processor produced from the detector's output of the same step.  With
+seeded random weights the detector's map carries no text structure, so each page's map is blended on the device with that page's
+synthetic text kernels (ground-truth line boxes shrunk by the DB shrink rule): inside a kernel 0.75 + 0.25 p, elsewhere 0.25 p, p = the
+detector's `binary` output.  The whole chain (D2H, contours, unclip, rectangles, H2D, padding of the last recogniser batch) is inside
+the timed region.  Images shard across ranks with no data-path collective (weak scaling); RCCL is used once, to broadcast the packed
+weight blobs from rank 0.
 
-Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for the roofline / cpu_baseline definitions).
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for the roofline / cpu_baseline / parity definitions).
 """
 import argparse
 import json
 import os
+import queue
+import socket
+import subprocess
 import sys
+import threading
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}  # dense MFMA peaks, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+PROFILE_ROUND = "r02"
 
 
 def parse():
@@ -35,7 +44,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--dtype", default=None, choices=["bf16", "f16", "f32"],
+                    help="MFMA operand type of both models for the headline.  Default: f32 (the parity mode, whose CTC strings equal the CPU "
+                         "reference's) followed by the --also mode; giving --dtype runs that one mode only")
+    ap.add_argument("--also", default="f16", choices=["f16", "bf16", "none"],
+                    help="16-bit throughput mode measured after the headline in the same process and reported as `throughput_mode`")
     ap.add_argument("--workload", default="e2e", choices=["e2e", "det", "rec"])
     ap.add_argument("--batch", type=int, default=64, help="invoices per rank per step (BASELINE.json configs[3])")
     ap.add_argument("--lines", type=int, default=30)
@@ -43,134 +56,33 @@ def parse():
     ap.add_argument("--rec-batch", type=int, default=256)
     ap.add_argument("--height", type=int, default=960)
     ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--boxes", default="detected", choices=["detected", "synthetic-gt"],
+                    help="detected: crops come from DB post-processing of the (blended) detector map inside the timed region; "
+                         "synthetic-gt: round-1 variant, ground-truth rectangles, no post-processing")
+    ap.add_argument("--post-threads", type=int, default=0, help="host threads for DB post-processing (0 = cores available / ranks, at most 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-check", action="store_true", help="skip the fp32-mode re-run of the last step's crops (CER of the benchmarked dtype)")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernel launches with HIP events")
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying captured HIP graphs")
-    ap.add_argument("--no-overlap", action="store_true",
-                    help="run detector and recogniser back to back on one stream instead of pipelining det(i+1) with rec(i) on two")
     return ap.parse_args()
 
 
-class Pipeline:
-    """The timed region.  Everything here goes through libocrvi's C ABI."""
-
-    def __init__(self, args, dev, det_sd, rec_sd):
-        from ocr_vi_invoice_amd import DBNetPP, SVTRv2, _lib
-        self.args, self.dev, self.L = args, dev, _lib
-        self.lib = _lib.load()
-        self.det = DBNetPP(pretrained=False, state_dict=det_sd, dtype=args.dtype, device=dev) if args.workload != "rec" else None
-        self.rec = SVTRv2("base", state_dict=rec_sd, dtype=args.dtype, device=dev) if args.workload != "det" else None
-        self.devi = torch.device(dev).index or 0
-
-    def load_inputs(self, images_u8, boxes):
-        a = self.args
-        self.images = torch.from_numpy(images_u8).to(self.dev)                 # [B,H,W,3] uint8, resident in HBM
-        self.boxes = torch.from_numpy(boxes).to(self.dev)                      # [B*lines,5] int32
-        self.x = torch.empty((a.det_chunk, 3, a.height, a.width), dtype=torch.float32, device=self.dev)
-        self.crops = torch.empty((boxes.shape[0], 3, 48, 320), dtype=torch.float32, device=self.dev)
-
-    # ---- the device work of one step, as plain enqueue-only calls (capturable: no allocation, no sync inside libocrvi)
-    def _det_chunk(self, i, n):
-        a, L, lib = self.args, self.L, self.lib
-        stream = torch.cuda.current_stream(self.dev).cuda_stream
-        L.check(lib.ocrvi_normalize_u8(self.devi, self.images[i:i + n].data_ptr(), n, a.height, a.width, self.x.data_ptr(), stream))
-        return self.det(self.x[:n])                                            # all five maps, as DBNetPP.forward returns
-
-    def _crop(self):
-        a, L, lib = self.args, self.L, self.lib
-        stream = torch.cuda.current_stream(self.dev).cuda_stream
-        L.check(lib.ocrvi_crop_resize_normalize(self.devi, self.images.data_ptr(), a.batch, a.height, a.width, self.boxes.data_ptr(),
-                                                self.boxes.shape[0], 48, 320, self.crops.data_ptr(), stream))
-
-    def _rec_chunk(self, i):
-        return self.rec._run(self.crops[i:i + self.args.rec_batch], False, True)[2:]   # (ids, lens) on device
-
-    def _device_step(self):
-        a = self.args
-        out, dec = None, []
-        if self.det is not None:
-            for i in range(0, a.batch, a.det_chunk):
-                out = self._det_chunk(i, min(a.det_chunk, a.batch - i))
-        if self.rec is not None:
-            self._crop()
-            for i in range(0, self.boxes.shape[0], a.rec_batch):
-                dec.append(self._rec_chunk(i))
-        return out, dec
-
-    def capture(self):
-        """Capture one whole step into a HIP graph (hipGraph replay removes ~150 host launches per recogniser forward)."""
-        self._device_step()                      # warm-up outside capture: sizes the workspaces, builds lazy state
-        torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.g_out, self.g_dec = self._device_step()
-
-    # ---- two-stream pipeline: det(i+1) runs concurrently with rec(i); rec(i) waits for det(i) by event (as it would have to if its
-    #      boxes came from det(i)'s map), ids go to pinned host memory on the rec stream, strings are built one step late.
-    def capture_overlap(self):
-        a = self.args
-        self._device_step()
-        torch.cuda.synchronize()
-        self.s_det, self.s_rec = torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev)
-        self.g_det, self.g_rec = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_det, stream=self.s_det):
-            for i in range(0, a.batch, a.det_chunk):
-                self.g_out = self._det_chunk(i, min(a.det_chunk, a.batch - i))
-        with torch.cuda.graph(self.g_rec, stream=self.s_rec):
-            self._crop()
-            self.g_dec = [self._rec_chunk(i) for i in range(0, self.boxes.shape[0], a.rec_batch)]
-            self.g_ids = torch.cat([d[0] for d in self.g_dec])
-            self.g_lens = torch.cat([d[1] for d in self.g_dec])
-        self.h_ids = [torch.empty(self.g_ids.shape, dtype=torch.int32).pin_memory() for _ in range(2)]
-        self.h_lens = [torch.empty(self.g_lens.shape, dtype=torch.int32).pin_memory() for _ in range(2)]
-        self.ev_det = [torch.cuda.Event() for _ in range(2)]
-        self.ev_rec = [torch.cuda.Event() for _ in range(2)]
-        self.pending = None
-        self.nstep = 0
-
-    def _collect(self, slot):
-        self.ev_rec[slot].synchronize()
-        ids, lens = self.h_ids[slot].tolist(), self.h_lens[slot].tolist()
-        return self.rec.tokenizer.decode([row[:n] for row, n in zip(ids, lens)])
-
-    def step_overlap(self):
-        """Enqueue step i on both streams; returns the strings of step i-1 (None on the first call)."""
-        k = self.nstep & 1
-        with torch.cuda.stream(self.s_det):
-            self.g_det.replay()
-            self.ev_det[k].record(self.s_det)
-        with torch.cuda.stream(self.s_rec):
-            self.s_rec.wait_event(self.ev_det[k])
-            self.g_rec.replay()
-            self.h_ids[k].copy_(self.g_ids, non_blocking=True)
-            self.h_lens[k].copy_(self.g_lens, non_blocking=True)
-            self.ev_rec[k].record(self.s_rec)
-        texts = self._collect(self.pending) if self.pending is not None else None
-        self.pending = k
-        self.nstep += 1
-        return self.g_out, texts
-
-    def flush_overlap(self):
-        texts = self._collect(self.pending) if self.pending is not None else None
-        self.pending = None
-        return texts
-
-    def step(self):
-        if getattr(self, "g_det", None) is not None:
-            return self.step_overlap()
-        if getattr(self, "graph", None) is not None:
-            self.graph.replay()
-            out, dec = self.g_out, self.g_dec
-        else:
-            out, dec = self._device_step()
-        texts = None
-        if self.rec is not None:                 # ids -> host -> strings (Tokenizer.decode semantics), part of the step
-            texts = []
-            for ids, lens in dec:
-                texts.extend(self.rec._ids_to_text(ids, lens))
-        return out, texts
+# ------------------------------------------------------------------------------------------------ launcher
+def launch_ranks(args):
+    """`python bench.py --gpus N` from a plain shell: start N fresh rank processes and relay their output.  Runs before this process
+    has imported torch.cuda state or libocrvi, and never re-execs: the children are ordinary subprocesses."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
 
 
+# ------------------------------------------------------------------------------------------------ helpers
 def edit_distance(a, b):
     prev = list(range(len(b) + 1))
     for i, ca in enumerate(a, 1):
@@ -181,11 +93,281 @@ def edit_distance(a, b):
     return prev[-1]
 
 
-def cpu_baseline(args, det_sd, rec_sd, image_u8, crops_dev, gpu_texts):
-    """Oracle (CPU restatement, `kind: port`) timed on this host on a bounded sample: ONE invoice through the detector and
-    `lines` of its crops through the recogniser in the reference's batching (1 image per det forward pipeline2.py:279-317,
-    32 crops per rec forward :221).  Also the CER of the GPU strings against the oracle's strings on that sample
-    (src/rec2/val.py:14-24 semantics)."""
+def cer(hyp, ref):
+    """src/rec2/val.py:14-24: sum of edit distances / sum of reference lengths."""
+    num = sum(edit_distance(h, r) for h, r in zip(hyp, ref))
+    return num / max(sum(len(r) for r in ref), 1)
+
+
+def shrink_box(x, y, w, h, ratio=0.4):
+    """DB's text-kernel shrink (the label rule behind the map the detector is trained to emit): offset D = A (1 - r^2) / L inwards."""
+    d = int(round(w * h * (1.0 - ratio * ratio) / (2.0 * (w + h))))
+    d = max(0, min(d, (min(w, h) - 3) // 2))
+    return x + d, y + d, w - 2 * d, h - 2 * d
+
+
+class E2E:
+    """The timed region.  Everything on the device goes through libocrvi's C ABI; the host stage is ocrvi_db_boxes_batch."""
+
+    def __init__(self, args, dev, det_blob, rec_blob, n_ranks_on_host):
+        import torch
+        from ocr_vi_invoice_amd import DBNetPP, SVTRv2, _lib
+        from ocr_vi_invoice_amd.pipeline import DBPostProcessor
+        self.torch, self.args, self.dev, self.L = torch, args, dev, _lib
+        self.lib = _lib.load()
+        self.det = DBNetPP(pretrained=False, blob=det_blob, dtype=args.dtype, device=dev) if args.workload != "rec" else None
+        self.rec = SVTRv2("base", blob=rec_blob, dtype=args.dtype, device=dev) if args.workload != "det" else None
+        self.devi = torch.device(dev).index or 0
+        # pipeline2.py:213-216,254-259 defaults: thresh 0.3, box_thresh 0.5, unclip 1.6, min_area 10
+        self.pp = DBPostProcessor(thresh=0.3, box_thresh=0.5, max_candidates=1000, unclip_ratio=1.6)
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        self.post_threads = args.post_threads or max(2, min(16, avail // max(n_ranks_on_host, 1)))
+        self.detected = args.boxes == "detected" and args.workload == "e2e"
+
+    # ---- inputs
+    def load_inputs(self, images_u8, gt_boxes):
+        import numpy as np
+        torch, a = self.torch, self.args
+        self.images = torch.from_numpy(images_u8).to(self.dev)                 # [B,H,W,3] uint8, resident in HBM
+        self.gt_rects = np.ascontiguousarray(gt_boxes, dtype=np.int32)          # [B*lines,5] (page, x, y, w, h)
+        self.x = torch.empty((a.det_chunk, 3, a.height, a.width), dtype=torch.float32, device=self.dev)
+        self.nchunk = (a.batch + a.det_chunk - 1) // a.det_chunk
+        if self.detected:
+            add = np.zeros((a.batch, 1, a.height, a.width), np.float32)
+            for pg, x, y, w, h in self.gt_rects:
+                sx, sy, sw, sh = shrink_box(int(x), int(y), int(w), int(h))
+                add[pg, 0, sy:sy + sh, sx:sx + sw] = 0.75
+            self.kernel_add = torch.from_numpy(add).to(self.dev)
+            self.prob = [torch.empty((min(a.det_chunk, a.batch - c * a.det_chunk), 1, a.height, a.width), dtype=torch.float32, device=self.dev)
+                         for c in range(self.nchunk)]
+            # two steps of pinned host maps in flight
+            self.h_prob = [[torch.empty(p.shape, dtype=torch.float32).pin_memory() for p in self.prob] for _ in range(2)]
+            self.ev_map = [[torch.cuda.Event() for _ in self.prob] for _ in range(2)]
+        if self.rec is not None:
+            rb = a.rec_batch
+            self.d_rects = torch.zeros((rb, 5), dtype=torch.int32, device=self.dev)
+            self.crops = torch.empty((rb, 3, 48, 320), dtype=torch.float32, device=self.dev)
+            nslots = 2 * ((a.batch * (a.lines + 8) + rb - 1) // rb + self.nchunk + 2)
+            self.h_rects = [torch.zeros((rb, 5), dtype=torch.int32).pin_memory() for _ in range(nslots)]
+            self.h_ids = [torch.empty((rb, 80), dtype=torch.int32).pin_memory() for _ in range(nslots)]
+            self.h_lens = [torch.empty((rb,), dtype=torch.int32).pin_memory() for _ in range(nslots)]
+            self.ev_rec = [torch.cuda.Event() for _ in range(nslots)]
+            self.slot = 0
+
+    # ---- device work as plain enqueue-only calls (capturable: no allocation, no sync inside libocrvi)
+    def _det_chunk(self, c):
+        a, L, lib, torch = self.args, self.L, self.lib, self.torch
+        i = c * a.det_chunk
+        n = min(a.det_chunk, a.batch - i)
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        L.check(lib.ocrvi_normalize_u8(self.devi, self.images[i:i + n].data_ptr(), n, a.height, a.width, self.x.data_ptr(), stream))
+        out = self.det(self.x[:n])                                             # all five maps, as DBNetPP.forward returns
+        if self.detected:                                                      # synthetic text kernels over the random-weight map
+            torch.add(self.kernel_add[i:i + n], out["binary"], alpha=0.25, out=self.prob[c])
+        return out
+
+    def _rec_batch(self):
+        a, L, lib, torch = self.args, self.L, self.lib, self.torch
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        L.check(lib.ocrvi_crop_resize_normalize(self.devi, self.images.data_ptr(), a.batch, a.height, a.width, self.d_rects.data_ptr(),
+                                                a.rec_batch, 48, 320, self.crops.data_ptr(), stream))
+        return self.rec._run(self.crops, False, True)[2:]                      # (ids, lens) on device
+
+    def capture(self):
+        torch, a = self.torch, self.args
+        self.s_det, self.s_rec = torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev)
+        self.g_det, self.g_rec = None, None
+        if self.det is not None:
+            with torch.cuda.stream(self.s_det):
+                for c in range(self.nchunk):
+                    self._det_chunk(c)                                         # warm-up outside capture: sizes the workspace
+            torch.cuda.synchronize()
+            if not a.no_graph:
+                self.g_det = []
+                for c in range(self.nchunk):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=self.s_det):
+                        self._det_chunk(c)
+                    self.g_det.append(g)
+        if self.rec is not None:
+            with torch.cuda.stream(self.s_rec):
+                self.g_ids, self.g_lens = self._rec_batch()
+            torch.cuda.synchronize()
+            if not a.no_graph:
+                self.g_rec = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.g_rec, stream=self.s_rec):
+                    self.g_ids, self.g_lens = self._rec_batch()
+        self.jobs = queue.Queue()
+        self.room = threading.Semaphore(2)      # the detector may run at most two steps ahead of the post-processor (pinned map ring)
+        self.results = queue.Queue()
+        self.worker = threading.Thread(target=self._worker, daemon=True)
+        self.worker.start()
+        self.nstep = 0
+
+    # ---- host side: post-process chunk by chunk, feed the recogniser, collect strings
+    def _enqueue_rec(self, rects, pending):
+        """rects: int32 [n,5]; full batches are launched, the remainder stays in `pending` (returned)."""
+        import numpy as np
+        torch, a = self.torch, self.args
+        rb = a.rec_batch
+        cat = rects if pending is None or not len(pending) else np.concatenate([pending, rects], 0)
+        launched = []
+        off = 0
+        while len(cat) - off >= rb:
+            launched.append(self._launch_rec(cat[off:off + rb], rb))
+            off += rb
+        return cat[off:], launched
+
+    def _launch_rec(self, rects, nvalid):
+        torch, a = self.torch, self.args
+        k = self.slot
+        self.slot = (self.slot + 1) % len(self.h_rects)
+        hr = self.h_rects[k].numpy()
+        hr[:nvalid] = rects[:nvalid]
+        if nvalid < a.rec_batch:
+            hr[nvalid:] = 0                      # w = h = 0: the all-zero tensor of pipeline2.py:154-156; its string is dropped
+        with torch.cuda.stream(self.s_rec):
+            self.d_rects.copy_(self.h_rects[k], non_blocking=True)
+            if self.g_rec is not None:
+                self.g_rec.replay()
+            else:
+                self.g_ids, self.g_lens = self._rec_batch()
+            self.h_ids[k].copy_(self.g_ids, non_blocking=True)
+            self.h_lens[k].copy_(self.g_lens, non_blocking=True)
+            self.ev_rec[k].record(self.s_rec)
+        return k, nvalid
+
+    def _strings(self, launched):
+        out = []
+        for k, nvalid in launched:
+            self.ev_rec[k].synchronize()
+            ids, lens = self.h_ids[k][:nvalid].tolist(), self.h_lens[k][:nvalid].tolist()
+            out.extend(self.rec.tokenizer.decode([row[:n] for row, n in zip(ids, lens)]))
+        return out
+
+    def _worker(self):
+        try:
+            self._worker_loop()
+        except BaseException as e:  # noqa: BLE001  (surface it in the main thread instead of hanging the run)
+            self.results.put(e)
+            for _ in range(4):
+                self.room.release()
+
+    def _worker_loop(self):
+        import numpy as np
+        from ocr_vi_invoice_amd.pipeline import db_boxes_batch
+        a = self.args
+        prev = None                              # (rects, launched batches) of the previous step: its strings are built one step late
+        while True:
+            job = self.jobs.get()
+            if job is None:
+                break
+            if job == "flush":
+                if prev is not None:
+                    self.results.put((prev[0], self._strings(prev[1]), prev[2]))
+                    prev = None
+                self.results.put("flushed")
+                continue
+            step = job
+            launched, pending, all_rects, counts = [], None, [], []
+            if self.detected:
+                for c in range(self.nchunk):
+                    self.ev_map[step & 1][c].synchronize()
+                    maps = self.h_prob[step & 1][c]
+                    rects, cnt, _ = db_boxes_batch(maps.view(maps.shape[0], a.height, a.width), self.pp, 1.0, 1.0, (a.height, a.width),
+                                                   page_base=c * a.det_chunk, threads=self.post_threads, cap_per_page=256)
+                    all_rects.append(rects)
+                    counts.extend(int(v) for v in cnt)
+                    if self.rec is not None:
+                        pending, l2 = self._enqueue_rec(rects, pending)
+                        launched += l2
+                self.room.release()
+            else:
+                rects = self.gt_rects
+                all_rects.append(rects)
+                if self.rec is not None:
+                    with self.torch.cuda.stream(self.s_rec):
+                        self.s_rec.wait_event(self.ev_det_done[step & 1])
+                    pending, launched = self._enqueue_rec(rects, None)
+                self.room.release()
+            if self.rec is not None and pending is not None and len(pending):
+                launched.append(self._launch_rec(pending, len(pending)))
+            if prev is not None:                 # strings of step-1 while step's recogniser batches run
+                self.results.put((prev[0], self._strings(prev[1]), prev[2]))
+            prev = (np.concatenate(all_rects, 0) if all_rects else None, launched, counts)
+
+    def step(self):
+        """Enqueue one step: the detector's chunks on its stream; everything downstream is driven by the worker thread."""
+        torch, a = self.torch, self.args
+        self.room.acquire()
+        k = self.nstep & 1
+        if self.det is not None:
+            with torch.cuda.stream(self.s_det):
+                for c in range(self.nchunk):
+                    if self.g_det is not None:
+                        self.g_det[c].replay()
+                    else:
+                        self._det_chunk(c)
+                    if self.detected:
+                        self.h_prob[k][c].copy_(self.prob[c], non_blocking=True)
+                        self.ev_map[k][c].record(self.s_det)
+                if not self.detected:
+                    if not hasattr(self, "ev_det_done"):
+                        self.ev_det_done = [torch.cuda.Event(), torch.cuda.Event()]
+                    self.ev_det_done[k].record(self.s_det)
+        elif not hasattr(self, "ev_det_done"):
+            self.ev_det_done = [torch.cuda.Event(), torch.cuda.Event()]
+            for e in self.ev_det_done:
+                e.record(self.s_rec)
+        self.jobs.put(self.nstep)
+        self.nstep += 1
+
+    def finish(self):
+        """Drain: returns the list of (rects, strings, boxes-per-page) of every step since the last finish()."""
+        self.jobs.put("flush")
+        out = []
+        while True:
+            r = self.results.get()
+            if isinstance(r, BaseException):
+                raise r
+            if isinstance(r, str) and r == "flushed":
+                break
+            out.append(r)
+        self.torch.cuda.synchronize()
+        return out
+
+    def close(self):
+        self.jobs.put(None)
+        self.worker.join(timeout=30)
+
+    # ---- one sequential eager pass of the same device work (per-kernel HIP-event timing; each kernel alone on the chip)
+    def eager_pass(self, rects):
+        import numpy as np
+        torch, a = self.torch, self.args
+        if self.det is not None:
+            for c in range(self.nchunk):
+                self._det_chunk(c)
+        if self.rec is not None and rects is not None:
+            rb = a.rec_batch
+            for off in range(0, len(rects), rb):
+                part = np.zeros((rb, 5), np.int32)
+                n = min(rb, len(rects) - off)
+                part[:n] = rects[off:off + n]
+                self.d_rects.copy_(torch.from_numpy(part))
+                self._rec_batch()
+        torch.cuda.synchronize()
+
+
+def cpu_baseline(args, det_sd, rec_sd, image_u8, crops_f32, gpu_texts):
+    """Oracle (CPU restatement, `kind: port`) timed on this host as SURVEY.md 8d prescribes: ONE full page through the detector and
+    32-crop batches through the recogniser (the reference's batching: 1 image per det forward pipeline2.py:279-317, 32 crops per rec
+    forward :221), one warm-up then the median of 3, torch.set_num_threads(cores available).  Also the CER of the GPU strings against
+    the oracle's strings on those 32 crops (src/rec2/val.py:14-24 semantics)."""
+    import numpy as np
+    import torch
     from ocr_vi_invoice_amd import synth
     from ocr_vi_invoice_amd.vocab import Tokenizer
     from oracle import dbnet_cpu, svtrv2_cpu
@@ -193,46 +375,131 @@ def cpu_baseline(args, det_sd, rec_sd, image_u8, crops_dev, gpu_texts):
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, min(avail, 16))   # a 1-GPU box gets a 16-core share of the host; more threads only oversubscribe
-    torch.set_num_threads(cores)
+    torch.set_num_threads(avail)
     t_det = t_rec = 0.0
     sample = []
     if args.workload != "rec":
-        # bounded sample: the top-left quarter (H/2 x W/2, still a multiple of 32) of one invoice; the detector is fully
-        # convolutional, so time scales with area -> x4 for one full page
-        hh, ww = args.height // 64 * 32, args.width // 64 * 32
-        x = torch.from_numpy(synth.normalize_chw(image_u8[:hh, :ww]))[None]
-        t0 = time.perf_counter()
-        dbnet_cpu.forward(det_sd, x)
-        t_det = (time.perf_counter() - t0) * (args.height * args.width) / (hh * ww)
-        sample.append(f"detector on a {hh}x{ww} quarter of one invoice, time scaled x{args.height * args.width / (hh * ww):.0f} to a full page")
-    cer = None
+        x = torch.from_numpy(synth.normalize_chw(image_u8))[None]
+        ts = []
+        for i in range(4):
+            t0 = time.perf_counter()
+            dbnet_cpu.forward(det_sd, x)
+            ts.append(time.perf_counter() - t0)
+        t_det = float(np.median(ts[1:]))
+        sample.append(f"detector: one full {args.height}x{args.width} page, 1 warm-up + median of 3")
+    cer_cpu = None
     if args.workload != "det":
-        n = min(args.lines, 8)
-        xc = crops_dev[:n].cpu()
-        t0 = time.perf_counter()
-        ref_txt = []
-        for i in range(0, n, 32):
-            lp = svtrv2_cpu.forward(rec_sd, xc[i:i + 32], "base")
-            ref_txt += Tokenizer().decode(svtrv2_cpu.greedy_ids(lp))
-        t_rec = (time.perf_counter() - t0) * args.lines / n
-        sample.append(f"{n} crops 48x320 through the recogniser, time scaled to {args.lines} crops/invoice")
-        num = sum(edit_distance(g, r) for g, r in zip(gpu_texts[:n], ref_txt))
-        cer = num / max(sum(len(r) for r in ref_txt), 1)
+        n = min(32, crops_f32.shape[0])
+        xc = crops_f32[:n].cpu()
+        ts, ref_txt = [], None
+        for i in range(4):
+            t0 = time.perf_counter()
+            lp = svtrv2_cpu.forward(rec_sd, xc, "base")
+            ref_txt = Tokenizer().decode(svtrv2_cpu.greedy_ids(lp))
+            ts.append(time.perf_counter() - t0)
+        t_rec = float(np.median(ts[1:])) * args.lines / n
+        sample.append(f"recogniser: one {n}-crop 48x320 batch, 1 warm-up + median of 3, scaled to {args.lines} crops/invoice")
+        cer_cpu = cer(gpu_texts[:n], ref_txt)
     total = t_det + t_rec
     if args.workload == "rec":
         val, unit = args.lines / total, "crops/s"
     else:
         val, unit = 1.0 / total, "images/s"
-    return {"value": round(val, 4), "unit": unit, "cores": cores, "kind": "port", "sample": "; ".join(sample),
-            "det_s": round(t_det, 2), "rec_s": round(t_rec, 2)}, cer
+    note = "DB post-processing and crop pre-processing are not in the CPU figure (the reference uses cv2/pyclipper there; absent here)"
+    return {"value": round(val, 4), "unit": unit, "cores": avail, "kind": "port", "sample": "; ".join(sample) + "; " + note,
+            "det_s": round(t_det, 3), "rec_s": round(t_rec, 3)}, cer_cpu
+
+
+def run_mode(args, dtype, dev, cdev, det_blob, rec_blob, images_u8, boxes, local_world, dist, lib):
+    """Warm-up + the timed region + one profiled eager pass for one compute dtype.  Returns a dict of raw results."""
+    import copy
+    import torch
+    from ocr_vi_invoice_amd import _lib
+    a = copy.copy(args)
+    a.dtype = dtype
+    pipe = E2E(a, dev, det_blob, rec_blob, local_world)
+    pipe.load_inputs(images_u8, boxes)
+    pipe.capture()
+    for _ in range(a.warmup):
+        pipe.step()
+    pipe.finish()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        pipe.step()
+    done = pipe.finish()                 # the last step's post-processing, recogniser batches and strings: inside the timed region
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist:
+        from ocr_vi_invoice_amd.dist import max_over_ranks
+        dt = max_over_ranks(dt, cdev, dist)
+    assert len(done) == a.steps, (len(done), a.steps)
+    last_rects, texts, counts = done[-1]
+    prof = {}
+    if not a.no_prof:
+        # graph nodes cannot carry per-kernel events, and under the two-stream pipeline a kernel's duration depends on what shares the
+        # chip with it: time the same kernels, shapes and buffers in ONE extra sequential eager pass right after the timed region
+        _lib.check(lib.ocrvi_prof_reset())
+        _lib.check(lib.ocrvi_prof_enable(1))
+        pipe.eager_pass(last_rects)
+        _lib.check(lib.ocrvi_prof_enable(0))
+        prof = _lib.prof_report()
+    out = {"dt": dt, "rects": last_rects, "texts": texts, "counts": counts, "prof": prof, "detected": pipe.detected,
+           "post_threads": pipe.post_threads, "images": pipe.images}
+    pipe.close()
+    return out
+
+
+def roofline_of(prof, dtype):
+    def roof(name, d):
+        secs = d["ms"] / 1e3
+        if d["flops"] > 0:
+            ach, peak, u, bound = d["flops"] / secs / 1e12, PEAK_TFLOPS[dtype], "TFLOP/s", "mfma"
+        else:
+            ach, peak, u, bound = d["bytes"] / secs / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
+        return {"kernel": name, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": u, "frac": round(ach / peak, 4)}
+    name, d = max(prof.items(), key=lambda kv: kv[1]["ms"])
+    traffic = None   # HBM-side bytes per launch from the PMC passes committed under profiles/ (separate rocprofv3 runs)
+    for rnd in (PROFILE_ROUND, "r01"):
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")))["kernels"].get(name)
+            if pmc:
+                traffic = pmc["traffic_bytes_per_launch"]
+                break
+        except (OSError, ValueError, KeyError):
+            pass
+    r = roof(name, d)
+    r.update({"traffic": traffic, "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"], 1), "launches": d["launches"],
+              "avg_ms": round(d["ms"] / d["launches"], 4), "algorithmic_flops_per_launch": round(d["flops"] / d["launches"], 1),
+              "timed_by": "HIP events on the launch stream around every launch, one sequential eager pass after the timed region"})
+    by = {k: {"frac": roof(k, v)["frac"], "bound": roof(k, v)["bound"], "ms": round(v["ms"], 3)}
+          for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+    tot = sum(v["ms"] for v in prof.values())
+    mf = sum(v["flops"] for v in prof.values())
+    return r, by, round(mf / (tot / 1e3) / 1e12, 2)
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+
+    import numpy as np
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (python bench.py --gpus N does it itself)")
+    # The headline is quoted in the mode whose CTC strings equal the CPU reference's: fp32 MFMA (DESIGN.md section 4 shows why no
+    # 16-bit mode can on the random-weight model).  The 16-bit throughput mode runs in the same process and is reported beside it.
+    primary = args.dtype or "f32"
+    secondary = None if (args.dtype is not None or args.also == "none" or args.also == primary) else args.also
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     # Rehearsal switch for a 1-GPU box: OCRVI_BENCH_REHEARSE=1 puts every rank on cuda:0 and uses gloo for the (CPU-side) collectives.
     rehearse = os.environ.get("OCRVI_BENCH_REHEARSE") == "1"
@@ -250,13 +517,19 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device(dev))  # RCCL over xGMI
 
-    # ---- weights: built on rank 0, broadcast once over RCCL (the only collective on the path)
-    det_sd = weights.make_det_state_dict(seed=1234)
-    rec_sd = weights.make_rec_state_dict("base", seed=1234)
+    # ---- weights: built, BN-folded and packed on rank 0 only; the packed blobs are broadcast once over RCCL (the only collective on
+    #      the path).  Every rank hands the same bytes to ocrvi_*_create.
+    det_sd = rec_sd = None
+    blobs = None
+    if rank == 0:
+        det_sd = weights.make_det_state_dict(seed=1234)
+        rec_sd = weights.make_rec_state_dict("base", seed=1234)
+        blobs = [weights.pack_blob(weights.fold_det(det_sd)), weights.pack_blob(weights.fold_rec(rec_sd, "base"))]
     bcast_ms = None
     if world > 1:
-        from ocr_vi_invoice_amd.dist import broadcast_weights
-        bcast_ms = broadcast_weights([det_sd, rec_sd], cdev, dist)
+        from ocr_vi_invoice_amd.dist import broadcast_blobs
+        blobs, bcast_ms = broadcast_blobs(blobs, cdev, dist)
+    det_blob, rec_blob = blobs
 
     # ---- synthetic inputs (this rank's shard)
     imgs, boxes = [], []
@@ -266,118 +539,72 @@ def main():
         boxes.append(np.concatenate([np.full((len(bx), 1), i, np.int32), bx], 1))
     images_u8 = np.stack(imgs)
     boxes = np.ascontiguousarray(np.concatenate(boxes, 0), dtype=np.int32)
-
-    pipe = Pipeline(args, dev, det_sd, rec_sd)
-    pipe.load_inputs(images_u8, boxes)
     lib = _lib.load()
 
-    overlap = not args.no_graph and not args.no_overlap and args.workload == "e2e"
-    if overlap:
-        pipe.capture_overlap()
-    elif not args.no_graph:
-        pipe.capture()
-    for _ in range(args.warmup):
-        pipe.step()
-    if overlap:
-        pipe.flush_overlap()
-    torch.cuda.synchronize()
-    graph_mode = getattr(pipe, "graph", None) is not None or overlap
-    if not args.no_prof and not graph_mode:      # eager: bracket every launch of the timed region with HIP events
-        _lib.check(lib.ocrvi_prof_reset())
-        _lib.check(lib.ocrvi_prof_enable(1))
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    texts = None
-    for _ in range(args.steps):
-        _, t = pipe.step()
-        texts = t if t is not None else texts
-    if overlap:
-        texts = pipe.flush_overlap()     # the last step's strings: still inside the timed region
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if dist:
-        from ocr_vi_invoice_amd.dist import max_over_ranks
-        dt = max_over_ranks(dt, cdev, dist)
-    prof, prof_steps = {}, args.steps
-    if not args.no_prof:
-        if graph_mode:
-            # graph nodes cannot carry per-kernel events: time the same kernels on the same stream in ONE extra eager step
-            _lib.check(lib.ocrvi_prof_reset())
-            _lib.check(lib.ocrvi_prof_enable(1))
-            pipe._device_step()   # sequential: each kernel alone on the chip, i.e. its intrinsic duration (under the two-stream
-                                  # pipeline of the timed region a kernel's duration depends on what it happens to share the chip with)
-            torch.cuda.synchronize()
-            prof_steps = 1
-        _lib.check(lib.ocrvi_prof_enable(0))
-        prof = _lib.prof_report()
+    m1 = run_mode(args, primary, dev, cdev, det_blob, rec_blob, images_u8, boxes, local_world, dist, lib)
+    m2 = run_mode(args, secondary, dev, cdev, det_blob, rec_blob, images_u8, boxes, local_world, dist, lib) if secondary else None
 
     if rank == 0:
-        units_per_step = args.batch if args.workload != "rec" else boxes.shape[0]
+        last_rects, texts, counts = m1["rects"], m1["texts"], m1["counts"]
+        n_crops = 0 if last_rects is None else len(last_rects)
+        units_per_step = args.batch if args.workload != "rec" else n_crops
         metric = {"e2e": "invoice images/sec end-to-end (det+rec)", "det": "detection images/sec", "rec": "recognition crops/sec"}[args.workload]
         unit = "crops/s" if args.workload == "rec" else "images/s"
+        boxes_note = ("boxes = DB post-processing (host, in the timed region) of the detector's binary map blended with synthetic text kernels"
+                      if m1["detected"] else "boxes=synthetic-gt, DB post-processing not timed")
         res = {
-            "metric": metric, "value": round(world * units_per_step * args.steps / dt, 3), "unit": unit,
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {args.batch} invoices/rank {args.height}x{args.width} -> DBNet++(ResNet-50-DCN, 5 maps) -> "
-                                   f"{args.lines} GT-box crops/invoice @48x320 -> SVTRv2-base -> CTC greedy (BASELINE.json configs[3]); "
-                                   f"boxes=synthetic-gt, DB post-processing not timed",
+            "metric": metric, "value": round(world * units_per_step * args.steps / m1["dt"], 3), "unit": unit,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(m1["dt"] / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": primary, "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {args.batch} invoices/rank {args.height}x{args.width} -> DBNet++(ResNet-50-DCN, 5 maps) -> D2H -> "
+                                   f"DB post-process -> crop rects -> H2D -> crop/resize @48x320 -> SVTRv2-base (batches of {args.rec_batch}) -> CTC greedy "
+                                   f"(BASELINE.json configs[3]); {boxes_note}",
                        "global_batch": world * args.batch, "det_chunk": args.det_chunk, "rec_batch": args.rec_batch,
-                       "weights": "seeded synthetic (no checkpoint ships)", "launch": "eager" if args.no_graph else ("hipGraph replay, det(i+1) || rec(i) on two streams" if overlap else "hipGraph replay"), "parallelism": f"replicas x{world}, images sharded, no collective"},
+                       "crops_per_step_rank0": n_crops, "boxes_per_page_min_max": [min(counts), max(counts)] if counts else None,
+                       "weights": "seeded synthetic (no checkpoint ships)",
+                       "launch": ("eager" if args.no_graph else "hipGraph replay") + ", det stream || host post-processing || rec stream",
+                       "post_process": {"in_timed_region": bool(m1["detected"]), "host_threads": m1["post_threads"]},
+                       "parallelism": f"replicas x{world}, images sharded, no collective"},
         }
         if bcast_ms is not None:
             res["weight_broadcast_ms"] = round(bcast_ms, 2)
-        # ---- roofline of the dominant kernel (most accumulated device time over the timed region)
-        if prof:
-            dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
-            name, d = dom
-            secs = d["ms"] / 1e3
-            if d["flops"] > 0:
-                ach, peak, u, bound = d["flops"] / secs / 1e12, PEAK_TFLOPS[args.dtype], "TFLOP/s", "mfma"
-            else:
-                ach, peak, u, bound = d["bytes"] / secs / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
-            traffic = None   # HBM-side bytes per launch from the PMC passes committed under profiles/ (separate rocprofv3 runs)
-            try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"].get(name)
-                traffic = pmc["traffic_bytes_per_launch"] if pmc else None
-            except (OSError, ValueError, KeyError):
-                pass
-            res["roofline"] = {"kernel": name, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": u, "frac": round(ach / peak, 4),
-                               "traffic": traffic, "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"], 1),
-                               "launches": d["launches"], "avg_ms": round(d["ms"] / d["launches"], 4),
-                               "algorithmic_flops_per_launch": round(d["flops"] / d["launches"], 1),
-                               "timed_by": "HIP events on the launch stream around every launch, " +
-                                           ("one extra sequential eager step after the graph-replayed timed region (rocprof cross-check: profiles/r01_bench_e2e_bf16_no_overlap_kernel_stats.csv)" if graph_mode else "over the timed region")}
-            tot = sum(v["ms"] for v in prof.values())
-            res["kernel_time_ms_per_step"] = {k: round(v["ms"] / prof_steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
-            mf = sum(v["flops"] for v in prof.values())
-            res["model_mfma_tflops"] = round(mf / (tot / 1e3) / 1e12, 2)
-        if world == 1 and args.workload == "e2e":
-            # SURVEY 8(f) row 1 (not in the timed region): the host DB post-processor on a detector-like map of one
-            # page (ground-truth line boxes rendered as blobs), through the C ABI, one core
-            try:
-                from ocr_vi_invoice_amd.pipeline import DBPostProcessor
-                pm = np.random.default_rng(0).uniform(0.0, 0.2, (args.height, args.width)).astype(np.float32)
-                for _, x, y, w, h in boxes[boxes[:, 0] == 0]:
-                    pm[y + 1:y + h - 1, x + 1:x + w - 1] = 0.9
-                pp = DBPostProcessor()
-                nb = len(pp(pm[None])[0])
-                t1 = time.perf_counter()
-                for _ in range(10):
-                    pp(pm[None])
-                res["db_postprocess_host"] = {"ms_per_page": round((time.perf_counter() - t1) / 10 * 1e3, 3), "boxes": nb, "cores": 1,
-                                              "in_timed_region": False}
-            except Exception as e:  # noqa: BLE001  (a reported extra, never fatal)
-                res["db_postprocess_host"] = {"error": str(e)[:120]}
+            res["weight_broadcast_bytes"] = len(det_blob) + len(rec_blob)
+        if m1["prof"]:
+            res["roofline"], res["roofline_by_kernel"], res["model_mfma_tflops"] = roofline_of(m1["prof"], primary)
+        # ---- parity of the headline dtype
+        crops_all = None
+        if args.workload != "det" and last_rects is not None and (not args.no_parity_check or not args.no_cpu_baseline):
+            from ocr_vi_invoice_amd.pipeline import preprocess_crops
+            crops_all = preprocess_crops(m1["images"], last_rects, (48, 320))
+        if args.workload != "det" and not args.no_parity_check and crops_all is not None and primary != "f32":
+            from ocr_vi_invoice_amd import SVTRv2
+            ref = SVTRv2("base", blob=rec_blob, dtype="f32", device=dev)
+            t32 = []
+            for i in range(0, crops_all.shape[0], args.rec_batch):
+                t32 += ref.decode_greedy(crops_all[i:i + args.rec_batch])
+            res["cer_vs_f32_mode"] = round(cer(texts, t32), 5)
+            res["strings_differ_vs_f32_mode"] = [sum(a != b for a, b in zip(texts, t32)), len(t32)]
+            del ref
+        if m2 is not None:
+            tm = {"dtype": secondary, "value": round(world * units_per_step * args.steps / m2["dt"], 3), "unit": unit,
+                  "ms_per_step": round(m2["dt"] / args.steps * 1e3, 3), "steps": args.steps, "warmup": args.warmup,
+                  "note": "same process, same inputs, same timed region as the headline; NOT string-identical to the CPU reference on the "
+                          "random-weight model (DESIGN.md section 4)"}
+            if m2["prof"]:
+                tm["roofline"], tm["roofline_by_kernel"], tm["model_mfma_tflops"] = roofline_of(m2["prof"], secondary)
+            if args.workload != "det" and m2["texts"] is not None and texts is not None:
+                same_rects = m2["rects"] is not None and last_rects is not None and np.array_equal(m2["rects"], last_rects)
+                tm["crop_rects_equal_headline"] = bool(same_rects)
+                if same_rects:
+                    tm["cer_vs_headline_strings"] = round(cer(m2["texts"], texts), 5)
+                    tm["strings_differ_vs_headline"] = [sum(x != y for x, y in zip(m2["texts"], texts)), len(texts)]
+            res["throughput_mode"] = tm
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only
-            cb, cer = cpu_baseline(args, det_sd, rec_sd, images_u8[0], pipe.crops if args.workload != "det" else None, texts)
+            cb, cer_cpu = cpu_baseline(args, det_sd, rec_sd, images_u8[0], crops_all, texts)
             res["cpu_baseline"] = cb
-            if cer is not None:
-                res["cer_vs_cpu_ref"] = round(cer, 4)
+            if cer_cpu is not None:
+                res["cer_vs_cpu_ref"] = round(cer_cpu, 5)
+                res["cer_vs_cpu_ref_crops"] = min(32, crops_all.shape[0])
         print(json.dumps(res), flush=True)
     if dist:
         dist.barrier()

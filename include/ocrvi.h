@@ -130,6 +130,15 @@ int ocrvi_crop_resize_normalize(int device, const uint8_t* images, int n_img, in
 int ocrvi_db_postprocess(const float* prob, int H, int W, float thresh, float box_thresh, int max_candidates, float unclip_ratio,
                          float min_area, int32_t* points, int cap_points, int32_t* box_offsets, float* scores, int cap_boxes, int* n_boxes);
 
+/* Replaces the host middle of the per-image loop for a batch of pages (src/pipeline/pipeline2.py:320-343): post_processor(prob_map)
+ * (src/det/test.py:55-106) on each of the n_pages host maps prob[n_pages][H][W] -> boxes divided by (scale_w, scale_h) with the int64
+ * truncation of pipeline2.py:324-328 -> crop_image's clamped bounding rectangle in the orig_h x orig_w page (src/det/test.py:123-130).
+ * rects[(page * cap_per_page + i) * 5] = (page_base + page, x, y, w, h) -- the layout ocrvi_crop_resize_normalize consumes --,
+ * scores (may be NULL) likewise, counts[page] = boxes of that page.  Pages are independent and run on `threads` host threads. */
+int ocrvi_db_boxes_batch(const float* prob, int n_pages, int H, int W, float thresh, float box_thresh, int max_candidates,
+                         float unclip_ratio, float min_area, double scale_w, double scale_h, int orig_h, int orig_w, int page_base,
+                         int32_t* rects, float* scores, int cap_per_page, int32_t* counts, int threads);
+
 /* ------------------------------------------------------------------------------------------------
  * Kernel-level test/bench hooks (same kernels the models launch; used by tests/ and bench.py for
  * per-kernel parity and roofline timing).

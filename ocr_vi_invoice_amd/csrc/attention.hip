@@ -199,11 +199,7 @@ static int launch_attn_m(const void* qkv, void* out, int B, int N, int heads, hi
     constexpr int NP = ((MAXT + 1) / 2) * 32;
     const int smem = NP * AttnCfg<T>::KROW + 32 * AttnCfg<T>::vstride(NP);
     auto kern = attention_kernel<T, MAXT, MASK>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        OCRVI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_done = true;
-    }
+    OCRVI_TRY(ensure_max_smem((const void*)kern, smem));
     hipLaunchKernelGGL(kern, dim3(heads, B), dim3(256), smem, s, (const T*)qkv, (T*)out, N, heads);
     OCRVI_HIP(hipGetLastError());
     return OCRVI_OK;

@@ -214,6 +214,21 @@ struct ProfScope {
 };
 static inline const char* dtype_name(int dt) { return dt == OCRVI_F32 ? "f32" : (dt == OCRVI_BF16 ? "bf16" : "f16"); }
 
+// ---------------------------------------------------------------- per-device launch state
+// CU count of the CURRENT device (cached per device id) and a once-per-(kernel, device) opt-in to > 64 KiB of dynamic LDS.
+int device_cus(int* n_cu);
+int ensure_max_smem(const void* kernel, int bytes);
+// Makes the handle's device current for the duration of a call and restores the caller's device afterwards.
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int dev) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) err = hipSetDevice(dev); else prev = -1;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 // Host fp32 -> T conversion into a byte buffer.
 void convert_to_dtype(const float* src, size_t n, int dtype, void* dst);
 

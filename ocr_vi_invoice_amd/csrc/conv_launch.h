@@ -27,11 +27,7 @@ template <typename T, int BM, int NW, int SPS, bool F32O, bool C3, int BN = 128>
 static int launch_ring_f(const ConvParams& p, int grid, hipStream_t stream) {
     constexpr int smem = 3 * (BM + BN) * 128 + 512;  // ring + bias
     auto kern = gemm_ring_kernel<T, BM, NW, SPS, F32O, C3, BN>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        OCRVI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_done = true;
-    }
+    OCRVI_TRY(ensure_max_smem((const void*)kern, smem));
 #ifdef OCRVI_RING_PROF_BUILD
     static const bool prof = getenv("OCRVI_RING_PROF") && atoi(getenv("OCRVI_RING_PROF"));
     if (prof) {  // development aid: cycle breakdown per phase, printed per launch (synchronises)
@@ -79,14 +75,8 @@ template <typename T>
 int launch_gemm_ring(const ConvParams& p_in, int amode, hipStream_t stream) {
     ConvParams p = p_in;
     OCRVI_TRY(ring_pages(&p.zero_page, &p.dump_page));
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        OCRVI_HIP(hipGetDevice(&dev));
-        OCRVI_HIP(hipGetDeviceProperties(&prop, dev));
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    int n_cu = 0;
+    OCRVI_TRY(device_cus(&n_cu));
     const int bn = p.Np % 128 == 0 ? 128 : 64;  // 64-channel layers: a 256x64 tile (16-bit types only, checked by gemm_ring_eligible)
     const int ntiles = p.Np / bn, nk = p.Kp / (int)(128 / sizeof(T));
     OCRVI_CHECK(ntiles >= 1 && ntiles <= n_cu && nk >= 1, OCRVI_EINVAL, "gemm_ring: Np=%d Kp=%d out of range", p.Np, p.Kp);

@@ -7,6 +7,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -55,9 +58,12 @@ void follow_border(signed char* f, int stride, int x0, int y0, bool is_hole, int
 // Labels: 0 background, 1 unvisited foreground, 2 visited border, -2 visited border whose east neighbour is background.  RETR_LIST
 // needs no per-border numbering, so one byte per pixel is enough; the padded label image is a per-thread buffer that is reused
 // across calls (a fresh multi-megabyte allocation per page costs more in page faults than the scan itself).
+// `label_buf` overrides the per-thread buffer (the batch entry point keeps one per worker slot across calls: its threads are short-lived).
+thread_local std::vector<signed char>* label_buf = nullptr;
 void find_contours(const float* prob, float thresh, int H, int W, std::vector<std::vector<Pt>>& contours) {
     const int stride = W + 2;
-    static thread_local std::vector<signed char> fbuf;
+    static thread_local std::vector<signed char> own;
+    std::vector<signed char>& fbuf = label_buf ? *label_buf : own;
     fbuf.resize((size_t)(H + 2) * stride);
     signed char* f = fbuf.data();
     memset(f, 0, stride);
@@ -368,5 +374,67 @@ extern "C" int ocrvi_db_postprocess(const float* prob, int H, int W, float thres
         box_offsets[++nb] = np;
     }
     *n_boxes = nb;
+    return OCRVI_OK;
+}
+
+// The host middle of the reference's per-image loop for a batch of pages (src/pipeline/pipeline2.py:320-343): DBPostProcessor on each
+// page's probability map -> boxes rescaled to the original image (int64 truncation of :324-328) -> the clamped bounding rectangle
+// crop_image slices (src/det/test.py:123-130).  Pages are independent, so they are spread over `threads` host threads (the reference
+// handles one page at a time in Python); everything stays in C so no interpreter lock is held.
+extern "C" int ocrvi_db_boxes_batch(const float* prob, int n_pages, int H, int W, float thresh, float box_thresh, int max_candidates,
+                                    float unclip_ratio, float min_area, double scale_w, double scale_h, int orig_h, int orig_w, int page_base,
+                                    int32_t* rects, float* scores, int cap_per_page, int32_t* counts, int threads) {
+    using namespace ocrvi;
+    OCRVI_CHECK(prob && rects && counts && n_pages > 0 && H > 0 && W > 0 && cap_per_page > 0 && scale_w > 0 && scale_h > 0 && orig_h > 0 && orig_w > 0,
+                OCRVI_EINVAL, "db_boxes_batch: bad argument");
+    std::atomic<int> next(0), failed(0);
+    static std::mutex pool_mu;                                  // one batch call at a time per process (it uses every core it is given anyway)
+    static std::vector<std::vector<signed char>> label_pool;    // padded label images, kept across calls (page faults cost more than the scan)
+    std::lock_guard<std::mutex> lk(pool_mu);
+    const int nt = std::max(1, std::min(threads, n_pages));
+    if ((int)label_pool.size() < nt) label_pool.resize(nt);
+    auto work = [&](int slot) {
+        label_buf = &label_pool[slot];
+        std::vector<int32_t> pts;
+        std::vector<int32_t> offs((size_t)cap_per_page + 1);
+        std::vector<float> sc((size_t)cap_per_page);
+        for (;;) {
+            const int pg = next.fetch_add(1);
+            if (pg >= n_pages) break;
+            int nb = 0, rc;
+            size_t cap_pts = (size_t)4 * (H + W) + 4096;
+            for (;;) {   // polygon vertex capacity is a guess: grow on OCRVI_ENOMEM
+                pts.resize(2 * cap_pts);
+                rc = ocrvi_db_postprocess(prob + (size_t)pg * H * W, H, W, thresh, box_thresh, max_candidates, unclip_ratio, min_area, pts.data(),
+                                          (int)cap_pts, offs.data(), sc.data(), cap_per_page, &nb);
+                if (rc != OCRVI_ENOMEM || cap_pts >= ((size_t)1 << 26)) break;
+                cap_pts *= 4;
+            }
+            if (rc != OCRVI_OK) { failed.store(rc); counts[pg] = 0; continue; }
+            int32_t* out = rects + (size_t)pg * cap_per_page * 5;
+            for (int b = 0; b < nb; ++b) {
+                long long x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+                for (int i = offs[b]; i < offs[b + 1]; ++i) {
+                    // rescaled_box[:, 0] = rescaled_box[:, 0] / scale_w into an integer array: C truncation toward zero; then astype(int32)
+                    const long long x = (long long)((double)pts[2 * i] / scale_w), y = (long long)((double)pts[2 * i + 1] / scale_h);
+                    if (i == offs[b]) { x0 = x1 = x; y0 = y1 = y; }
+                    x0 = std::min(x0, x); x1 = std::max(x1, x); y0 = std::min(y0, y); y1 = std::max(y1, y);
+                }
+                const long long bw = x1 - x0 + 1, bh = y1 - y0 + 1;          // cv2.boundingRect of integer points is inclusive
+                const long long cx = std::max(0LL, x0), cy = std::max(0LL, y0);
+                const long long cw = std::max(0LL, std::min(bw, (long long)orig_w - cx)), ch = std::max(0LL, std::min(bh, (long long)orig_h - cy));
+                out[5 * b] = page_base + pg; out[5 * b + 1] = (int32_t)cx; out[5 * b + 2] = (int32_t)cy; out[5 * b + 3] = (int32_t)cw; out[5 * b + 4] = (int32_t)ch;
+                if (scores) scores[(size_t)pg * cap_per_page + b] = sc[b];
+            }
+            counts[pg] = nb;
+        }
+        label_buf = nullptr;
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (auto& t : pool) t.join();
+    const int rc = failed.load();
+    OCRVI_CHECK(rc == OCRVI_OK, rc, "db_boxes_batch: a page failed (%s)", ocrvi_last_error());
     return OCRVI_OK;
 }

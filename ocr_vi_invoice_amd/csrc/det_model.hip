@@ -139,16 +139,21 @@ static int det_run(ocrvi_det* h, Runner& r, const float* x, int N, int H, int W,
     }
     Tensor cur = r.alloc(N, H / 4, W / 4, 64);
     if (!r.dry()) OCRVI_TRY(k_maxpool3x3s2(dt, s.p, cur.p, N, H / 2, W / 2, 64, r.stream));
-    // ---- layers 1..4
+    // ---- layers 1..4.  Block outputs ping-pong between two slots per layer (sized for the layer's output); the last block of a
+    // layer writes a fresh buffer that stays live as the c2..c5 tap (backbone.py:56-60).  Temporaries of a block are released
+    // when it ends, so a chunk of 16 pages keeps ~4 GB less live than with one buffer per block.
     Tensor feats[4];
     for (int li = 0; li < 4; ++li) {
         const int w = kWidth[li];
         const int nb = (int)h->layers[li].size();
+        const int lh = cur.h / h->layers[li][0].stride, lw = cur.w / h->layers[li][0].stride;
+        Tensor tap = r.alloc(N, lh, lw, 4 * w);                       // the layer's final output
+        const size_t slot_mark = r.arena.mark();
+        Tensor slot[2] = {r.alloc(N, lh, lw, 4 * w), r.alloc(N, lh, lw, 4 * w)};
         for (int b = 0; b < nb; ++b) {
             const Bottleneck& bk = h->layers[li][b];
             const int oh = cur.h / bk.stride, ow = cur.w / bk.stride;
-            const size_t mark = r.arena.mark();
-            Tensor y = r.alloc(N, oh, ow, 4 * w);  // block output (allocated first so it survives the release below)
+            Tensor y = b == nb - 1 ? tap : slot[b & 1];               // never the buffer `cur` lives in (slot[(b-1)&1] or the previous tap)
             const size_t mark2 = r.arena.mark();
             Tensor t1 = r.alloc(N, cur.h, cur.w, w);
             Tensor t2 = r.alloc(N, oh, ow, w);
@@ -184,10 +189,10 @@ static int det_run(ocrvi_det* h, Runner& r, const float* x, int N, int H, int W,
                 o.act = ACT_RELU; o.res = &idn; o.res_mode = RES_SAME;
                 OCRVI_TRY(conv(r, bk.conv3, t2, y, o));
             }
-            r.arena.release(mark2);  // t1, t2, offsets, downsample are dead; y stays
-            (void)mark;
+            r.arena.release(mark2);  // t1, t2, offsets, downsample are dead
             cur = y;
         }
+        r.arena.release(slot_mark);  // both slots are dead once the layer's last block has written the tap
         feats[li] = cur;
         h->tap_c[li] = cur;
     }
@@ -242,6 +247,8 @@ extern "C" int ocrvi_det_forward(ocrvi_det* h, const float* x, int N, int H, int
                                  float* bin_logits, float* thresh_logits, void* workspace, size_t workspace_bytes, void* stream) {
     OCRVI_TRY(check_det_shape(h, N, H, W));
     OCRVI_CHECK(x && binary && workspace, OCRVI_EINVAL, "det_forward: x, binary and workspace are required");
+    DeviceGuard dg(h->device);  // launches go to the handle's device whatever the caller's current device is
+    OCRVI_HIP(dg.err);
     size_t need = 0;
     OCRVI_TRY(ocrvi_det_workspace_bytes(h, N, H, W, &need));
     OCRVI_CHECK(workspace_bytes >= need, OCRVI_ENOMEM, "det_forward: workspace %zu < %zu bytes", workspace_bytes, need);
@@ -256,6 +263,8 @@ extern "C" int ocrvi_det_debug_features(ocrvi_det* h, int N, int H, int W, float
                                         void* workspace, size_t workspace_bytes, void* stream) {
     OCRVI_TRY(check_det_shape(h, N, H, W));
     OCRVI_CHECK(h->tap_fused.p, OCRVI_EINVAL, "det_debug_features: no forward has run");
+    DeviceGuard dg(h->device);
+    OCRVI_HIP(dg.err);
     (void)workspace; (void)workspace_bytes;
     float* outs[4] = {c2, c3, c4, c5};
     for (int i = 0; i < 4; ++i) {

@@ -199,26 +199,18 @@ static int launch_gconv32(const ConvParams& p, hipStream_t stream) {
     const int bands_x = cdiv(p.W, 16 * nbx), bands_y = cdiv(p.H, th);
     const int smem = (th + 2) * (16 * nbx + 2) * GC_PS + 9 * 32 * GC_PS;
     const unsigned hw_magic = 65536u / (unsigned)(16 * nbx + 2) + 1;  // pix / HW == (pix * magic) >> 16 for pix < 2^11
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        OCRVI_HIP(hipGetDevice(&dev));
-        OCRVI_HIP(hipGetDeviceProperties(&prop, dev));
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    int n_cu = 0;
+    OCRVI_TRY(device_cus(&n_cu));
     const int ntile = p.n_img * bands_y * bands_x;
     const int per_group = std::max(1, 2 * n_cu / p.groups);                  // two persistent workgroups per CU over all groups
     const dim3 grid(cdiv(ntile, cdiv(ntile, per_group)), p.groups);          // equal tile counts
     if (p.out_f32) {
         auto k = gconv32_kernel<T, true>;
-        static bool done = false;
-        if (!done) { OCRVI_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)); done = true; }
+        OCRVI_TRY(ensure_max_smem((const void*)k, 80 * 1024));
         hipLaunchKernelGGL(k, grid, dim3(256), smem, stream, p, th, nbx, bands_y, bands_x, hw_magic);
     } else {
         auto k = gconv32_kernel<T, false>;
-        static bool done = false;
-        if (!done) { OCRVI_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)); done = true; }
+        OCRVI_TRY(ensure_max_smem((const void*)k, 80 * 1024));
         hipLaunchKernelGGL(k, grid, dim3(256), smem, stream, p, th, nbx, bands_y, bands_x, hw_magic);
     }
     OCRVI_HIP(hipGetLastError());

@@ -220,6 +220,36 @@ bool gemm_ring_eligible(const ConvParams& p, int amode, int dtype) {
     return true;
 }
 
+int device_cus(int* n_cu) {
+    static std::mutex mu;
+    static std::map<int, int> cus;
+    std::lock_guard<std::mutex> lk(mu);
+    int dev = 0;
+    OCRVI_HIP(hipGetDevice(&dev));
+    auto it = cus.find(dev);
+    if (it == cus.end()) {
+        hipDeviceProp_t prop;
+        OCRVI_HIP(hipGetDeviceProperties(&prop, dev));
+        it = cus.emplace(dev, prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256).first;
+    }
+    *n_cu = it->second;
+    return OCRVI_OK;
+}
+
+int ensure_max_smem(const void* kernel, int bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, int> done;   // (kernel, device) -> largest size already granted
+    std::lock_guard<std::mutex> lk(mu);
+    int dev = 0;
+    OCRVI_HIP(hipGetDevice(&dev));
+    auto key = std::make_pair(kernel, dev);
+    auto it = done.find(key);
+    if (it != done.end() && it->second >= bytes) return OCRVI_OK;
+    OCRVI_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done[key] = bytes;
+    return OCRVI_OK;
+}
+
 int ring_pages(const void** zero_page, void** dump_page) {
     // one 8 KiB device allocation per process and device: [0, 4096) zeros, [4096, 8192) write sink.  Never freed.
     static std::mutex mu;

@@ -51,7 +51,12 @@ __global__ void crop_resize_normalize_kernel(const uint8_t* __restrict__ images,
         const size_t t = i / ow;
         const int y = (int)(t % oh), b = (int)(t / oh);
         const int32_t* bx = boxes + (size_t)b * 5;
-        const int img = bx[0], cx = bx[1], cy = bx[2], cw = bx[3], ch = bx[4];
+        const int img = bx[0];
+        // clamp the rectangle to the page exactly as crop_image does (src/det/test.py:126-129: x = max(0, x); bw = min(bw, w - x) --
+        // the width is NOT reduced by the shift).  Boxes live in HBM, so the host cannot validate them; a rectangle that ends up
+        // empty takes the zero-tensor path below
+        const int cx = max(bx[1], 0), cy = max(bx[2], 0);
+        const int cw = min(bx[3], W - cx), ch = min(bx[4], H - cy);
         float* o = out + ((size_t)b * 3 * oh + y) * ow + x;
         const size_t plane = (size_t)oh * ow;
         if (cw <= 0 || ch <= 0 || img < 0 || img >= n_img) {  // empty crop -> zeros tensor (pipeline2.py:154-156)

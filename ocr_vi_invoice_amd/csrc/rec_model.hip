@@ -301,6 +301,8 @@ extern "C" int ocrvi_rec_forward(ocrvi_rec* h, const float* x, int B, int H, int
                                  int32_t* lens, void* workspace, size_t workspace_bytes, void* stream) {
     OCRVI_TRY(check_rec_shape(h, B, H, W));
     OCRVI_CHECK(x && workspace, OCRVI_EINVAL, "rec_forward: null input/workspace");
+    DeviceGuard dg(h->device);  // launches go to the handle's device whatever the caller's current device is
+    OCRVI_HIP(dg.err);
     size_t need = 0;
     OCRVI_TRY(ocrvi_rec_workspace_bytes(h, B, H, W, &need));
     OCRVI_CHECK(workspace_bytes >= need, OCRVI_ENOMEM, "rec_forward: workspace %zu < %zu bytes", workspace_bytes, need);
@@ -315,6 +317,8 @@ extern "C" int ocrvi_rec_debug_features(ocrvi_rec* h, int B, int H, int W, float
                                         size_t workspace_bytes, void* stream) {
     OCRVI_TRY(check_rec_shape(h, B, H, W));
     OCRVI_CHECK(h->tap_bn && h->tap_frm, OCRVI_EINVAL, "rec_debug_features: no forward has run");
+    DeviceGuard dg(h->device);
+    OCRVI_HIP(dg.err);
     (void)workspace; (void)workspace_bytes;
     const int d = h->cfg.dims[2];
     const size_t ntok = (size_t)B * (H / 16) * (W / 4), ncol = (size_t)B * (W / 4);

@@ -12,7 +12,8 @@ from . import _lib, weights
 
 class DBNetPP:
     def __init__(self, backbone: str = "resnet50", pretrained: bool = False, in_channels: int = 3, inner_channels: int = 256,
-                 k: float = 50, dcn: bool = True, *, state_dict=None, seed: int = 1234, dtype="bf16", device="cuda:0"):
+                 k: float = 50, dcn: bool = True, *, state_dict=None, blob: bytes = None, seed: int = 1234, dtype="bf16",
+                 device="cuda:0"):
         if backbone != "resnet50":
             # the reference also offers resnet18 (backbone.py:12-15); the pipeline only uses resnet50 (pipeline2.py:45)
             raise NotImplementedError(f"Backbone {backbone} not implemented")
@@ -27,10 +28,31 @@ class DBNetPP:
         self._handle = None
         self._ws = {}
         self.training = False
-        self.load_state_dict(state_dict if state_dict is not None else weights.make_det_state_dict(seed))
+        if blob is not None:        # already folded + packed (weights.pack_blob): what rank 0 broadcasts to the other ranks
+            self.load_blob(blob)
+        else:
+            self.load_state_dict(state_dict if state_dict is not None else weights.make_det_state_dict(seed))
 
     def load_state_dict(self, state_dict, strict: bool = True):
-        blob = weights.pack_blob(weights.fold_det(state_dict))
+        """nn.Module.load_state_dict semantics for the keys the inference graph uses: with ``strict`` (default) a missing tensor
+        raises KeyError-as-RuntimeError like torch does; unexpected keys (the reference's duplicate ``backbone.layerN`` aliases, the
+        unused ``fc``, optimizer state in a wrapped checkpoint) are ignored, as the reference's loader effectively does."""
+        try:
+            folded = weights.fold_det(state_dict)
+        except KeyError as e:
+            if strict:
+                raise RuntimeError(f"Error(s) in loading state_dict for DBNetPP: missing key {e}") from None
+            raise
+        self._state = {k: (v.detach().clone() if isinstance(v, torch.Tensor) else v) for k, v in weights.unwrap_checkpoint(state_dict).items()}
+        return self.load_blob(weights.pack_blob(folded))
+
+    def state_dict(self):
+        """The state_dict this model was loaded from (reference key schema); None-safe copy."""
+        if getattr(self, "_state", None) is None:
+            raise RuntimeError("model was built from a packed blob; no state_dict is retained")
+        return dict(self._state)
+
+    def load_blob(self, blob: bytes):
         cfg = _lib.DetCfg()
         cfg.dtype = self.dtype
         cfg.k = self.k
@@ -39,11 +61,20 @@ class DBNetPP:
         _lib.check(_lib.load().ocrvi_det_create(self._dev_index(), blob, len(blob), C.byref(cfg), C.byref(h)))
         self._free()
         self._handle = h
+        self._blob = blob
         return self
 
     def to(self, device):
-        if torch.device(device) != self.device:
-            raise ValueError("the handle is bound to its device at construction; pass device= to the constructor")
+        """Moves the model like nn.Module.to: a different device re-creates the handle there from the retained weights."""
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise ValueError("libocrvi has no CPU path: the product runs on an MI355X (use the reference module for CPU)")
+        if dev != self.device:
+            if getattr(self, "_blob", None) is None:
+                raise RuntimeError("no weights retained to move")
+            self.device = dev
+            self._ws = {}
+            self.load_blob(self._blob)
         return self
 
     def eval(self):

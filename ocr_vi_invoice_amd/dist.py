@@ -47,6 +47,41 @@ def broadcast_weights(sds: List[MutableMapping[str, torch.Tensor]], device, dist
     return ms
 
 
+def broadcast_blobs(blobs, device, dist):
+    """The one collective of the sharded path: rank 0's packed weight blobs (``weights.pack_blob`` output: BN already
+    folded, one flat byte string per model) go to every rank in ONE broadcast, so no other rank builds, folds or packs anything.
+    ``blobs``: list of bytes on rank 0, ignored elsewhere.  Returns (list of bytes, broadcast wall time in ms)."""
+    import time
+    rank = dist.get_rank()
+    sizes = torch.zeros(8, dtype=torch.int64, device=device)
+    if rank == 0:
+        assert len(blobs) <= 7
+        sizes[0] = len(blobs)
+        for i, b in enumerate(blobs):
+            sizes[1 + i] = len(b)
+    dist.broadcast(sizes, 0)
+    n = int(sizes[0].item())
+    lens = [int(v) for v in sizes[1:1 + n].tolist()]
+    if rank == 0:
+        import numpy as np
+        flat = torch.from_numpy(np.frombuffer(b"".join(blobs), dtype=np.uint8).copy()).to(device)
+    else:
+        flat = torch.empty(sum(lens), dtype=torch.uint8, device=device)
+    if flat.is_cuda:
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dist.broadcast(flat, 0)
+    if flat.is_cuda:
+        torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3
+    raw = flat.cpu().numpy().tobytes()
+    out, off = [], 0
+    for ln in lens:
+        out.append(raw[off:off + ln])
+        off += ln
+    return out, ms
+
+
 def max_over_ranks(seconds: float, device, dist) -> float:
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -24,16 +24,38 @@ from .det import DBNetPP
 from .rec import SVTRv2
 
 
+def _numpy_data_globals():
+    """Data-only numpy reconstructors a reference-trained checkpoint carries next to ``model_state_dict``: the trainers store
+    ``best_f1`` / ``best_acc`` and ``val_metrics`` as numpy scalars (src/det/val.py:111-115 -> src/det/train.py:266-272,
+    src/rec2/train.py:237-260).  Allow-listing them keeps ``weights_only=True`` (nothing in the file is executed)."""
+    allow = [np.dtype]
+    try:
+        from numpy._core.multiarray import scalar
+    except ImportError:  # numpy < 2
+        from numpy.core.multiarray import scalar
+    allow.append(scalar)
+    for name in ("Float64DType", "Float32DType", "Float16DType", "Int64DType", "Int32DType", "BoolDType", "UInt8DType"):
+        t = getattr(getattr(np, "dtypes", None), name, None)
+        if t is not None:
+            allow.append(t)
+    return allow
+
+
+def load_checkpoint(model_path: str):
+    """torch.load of a reference checkpoint file with the weights-only unpickler; returns whatever the file holds (a wrapped dict with
+    ``model_state_dict`` or a bare state_dict -- ``weights.unwrap_checkpoint`` takes either, pipeline2.py:46-52,75-80)."""
+    with torch.serialization.safe_globals(_numpy_data_globals()):
+        return torch.load(model_path, map_location="cpu", weights_only=True)
+
+
 def load_detection_model(model_path: str, device: str = "cuda:0", dtype: str = "bf16") -> DBNetPP:
     """pipeline2.py:43-67.  The checkpoint is read with ``weights_only=True`` (nothing in the file is executed)."""
-    ckpt = torch.load(model_path, map_location="cpu", weights_only=True)
-    return DBNetPP(pretrained=False, state_dict=ckpt, device=device, dtype=dtype)
+    return DBNetPP(pretrained=False, state_dict=load_checkpoint(model_path), device=device, dtype=dtype)
 
 
 def load_recognition_model(model_path: str, device: str = "cuda:0", variant: str = "base", dtype: str = "bf16") -> SVTRv2:
     """pipeline2.py:72-89."""
-    ckpt = torch.load(model_path, map_location="cpu", weights_only=True)
-    return SVTRv2(variant=variant, in_channels=3, state_dict=ckpt, device=device, dtype=dtype)
+    return SVTRv2(variant=variant, in_channels=3, state_dict=load_checkpoint(model_path), device=device, dtype=dtype)
 
 
 def _dev_index(device) -> int:
@@ -110,6 +132,35 @@ class DBPostProcessor:
             break
         boxes = [points[offs[i]:offs[i + 1]].astype(np.int64) for i in range(n.value)]
         return boxes, [float(v) for v in scores[:n.value]]
+
+
+def db_boxes_batch(prob_maps, post_processor: "DBPostProcessor", scale_w: float = 1.0, scale_h: float = 1.0, orig_hw: Tuple[int, int] = None,
+                   page_base: int = 0, threads: int = 8, cap_per_page: int = None, out=None):
+    """The host middle of pipeline2.py:320-343 for a batch of pages, in one GIL-free call: ``post_processor`` on each map ->
+    ``rescale_boxes`` -> ``crop_rect``.  ``prob_maps``: float32 [n,H,W] host array (numpy, or a CPU/pinned torch tensor).
+    Returns (rects int32 [total,5] = (page, x, y, w, h) in page order, counts int32 [n], scores float32 [total])."""
+    if isinstance(prob_maps, torch.Tensor):
+        assert not prob_maps.is_cuda and prob_maps.dtype == torch.float32 and prob_maps.is_contiguous()
+        n, H, W = prob_maps.shape[-3:] if prob_maps.dim() >= 3 else (1,) + tuple(prob_maps.shape)
+        ptr = prob_maps.data_ptr()
+    else:
+        prob_maps = np.ascontiguousarray(prob_maps, dtype=np.float32)
+        if prob_maps.ndim == 2:
+            prob_maps = prob_maps[None]
+        n, H, W = prob_maps.shape
+        ptr = prob_maps.ctypes.data
+    oh, ow = orig_hw if orig_hw is not None else (H, W)
+    cap = int(cap_per_page or post_processor.max_candidates)
+    if out is None:
+        out = (np.empty((n, cap, 5), np.int32), np.empty((n, cap), np.float32), np.empty(n, np.int32))
+    rects, scores, counts = out
+    _lib.check(_lib.load().ocrvi_db_boxes_batch(ptr, n, H, W, float(post_processor.thresh), float(post_processor.box_thresh),
+                                                int(post_processor.max_candidates), float(post_processor.unclip_ratio),
+                                                float(post_processor.min_area), float(scale_w), float(scale_h), int(oh), int(ow), int(page_base),
+                                                rects.ctypes.data, scores.ctypes.data, cap, counts.ctypes.data, int(threads)))
+    keep = [rects[i, :counts[i]] for i in range(n)]
+    return (np.concatenate(keep, 0) if keep else np.empty((0, 5), np.int32)), counts[:n].copy(), \
+        np.concatenate([scores[i, :counts[i]] for i in range(n)], 0)
 
 
 def rescale_boxes(boxes, scale_w: float, scale_h: float) -> List[np.ndarray]:

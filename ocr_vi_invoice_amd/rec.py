@@ -14,7 +14,7 @@ from .vocab import VOCAB, Tokenizer
 
 class SVTRv2:
     def __init__(self, variant: str = "small", in_channels: int = 3, charset=VOCAB, dropout: float = 0.0,
-                 context_window: int = 3, *, state_dict=None, seed: int = 1234, dtype="bf16", device="cuda:0"):
+                 context_window: int = 3, *, state_dict=None, blob: bytes = None, seed: int = 1234, dtype="bf16", device="cuda:0"):
         assert variant in weights.REC_VARIANTS, \
             f"Unknown variant: {variant}. Choose from {list(weights.REC_VARIANTS.keys())}"  # svtrv2.py:425
         if in_channels != 3:
@@ -30,11 +30,30 @@ class SVTRv2:
         self._handle = None
         self._ws = {}
         self.training = False
-        self.load_state_dict(state_dict if state_dict is not None else weights.make_rec_state_dict(variant, seed))
+        if blob is not None:        # already folded + packed (weights.pack_blob): what rank 0 broadcasts to the other ranks
+            self.load_blob(blob)
+        else:
+            self.load_state_dict(state_dict if state_dict is not None else weights.make_rec_state_dict(variant, seed))
 
     # ---- nn.Module-like surface used by the pipeline (pipeline2.py:72-82)
     def load_state_dict(self, state_dict, strict: bool = True):
-        blob = weights.pack_blob(weights.fold_rec(state_dict, self.variant))
+        """nn.Module.load_state_dict semantics for the inference keys: a missing tensor raises RuntimeError when ``strict``; the
+        training-only ``sgm.*`` keys (svtrv2.py:252-385) and checkpoint wrappers are ignored."""
+        try:
+            folded = weights.fold_rec(state_dict, self.variant)
+        except KeyError as e:
+            if strict:
+                raise RuntimeError(f"Error(s) in loading state_dict for SVTRv2: missing key {e}") from None
+            raise
+        self._state = {k: (v.detach().clone() if isinstance(v, torch.Tensor) else v) for k, v in weights.unwrap_checkpoint(state_dict).items()}
+        return self.load_blob(weights.pack_blob(folded))
+
+    def state_dict(self):
+        if getattr(self, "_state", None) is None:
+            raise RuntimeError("model was built from a packed blob; no state_dict is retained")
+        return dict(self._state)
+
+    def load_blob(self, blob: bytes):
         cfg = _lib.RecCfg()
         v = weights.REC_VARIANTS[self.variant]
         cfg.dtype = self.dtype
@@ -48,11 +67,20 @@ class SVTRv2:
         _lib.check(lib.ocrvi_rec_create(self._dev_index(), blob, len(blob), C.byref(cfg), C.byref(h)))
         self._free()
         self._handle = h
+        self._blob = blob
         return self
 
     def to(self, device):
-        if torch.device(device) != self.device:
-            raise ValueError("the handle is bound to its device at construction; pass device= to the constructor")
+        """Moves the model like nn.Module.to: a different device re-creates the handle there from the retained weights."""
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise ValueError("libocrvi has no CPU path: the product runs on an MI355X (use the reference module for CPU)")
+        if dev != self.device:
+            if getattr(self, "_blob", None) is None:
+                raise RuntimeError("no weights retained to move")
+            self.device = dev
+            self._ws = {}
+            self.load_blob(self._blob)
         return self
 
     def eval(self):

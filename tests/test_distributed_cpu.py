@@ -8,7 +8,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from ocr_vi_invoice_amd import weights
-from ocr_vi_invoice_amd.dist import broadcast_weights, flatten_state_dicts, max_over_ranks, shard_range
+from ocr_vi_invoice_amd.dist import broadcast_blobs, broadcast_weights, flatten_state_dicts, max_over_ranks, shard_range
 
 
 def _free_port():
@@ -29,7 +29,14 @@ def _worker(rank, world, port, q):
         dtype_ok = sds[0]["stem.bn1.num_batches_tracked"].dtype == torch.long
         slow = max_over_ranks(1.0 + rank, "cpu", dist)      # the slowest rank defines the step time
         lo, hi = shard_range(13, rank, world)
-        q.put((rank, same, dtype_ok, slow, lo, hi, ms >= 0))
+        # the designed collective: rank 0 folds + packs, everybody receives the same bytes; other ranks build nothing
+        mine = None
+        if rank == 0:
+            mine = [weights.pack_blob(weights.fold_rec(weights.make_rec_state_dict("tiny", seed=100), "tiny")), b"second-blob"]
+        got, bms = broadcast_blobs(mine, "cpu", dist)
+        want_blob = weights.pack_blob(weights.fold_rec(weights.make_rec_state_dict("tiny", seed=100), "tiny"))
+        blob_ok = got[0] == want_blob and got[1] == b"second-blob" and bms >= 0
+        q.put((rank, same, dtype_ok, slow, lo, hi, ms >= 0 and blob_ok))
     finally:
         dist.destroy_process_group()
 
@@ -49,6 +56,48 @@ def test_weight_broadcast_sharding_and_timing_world2():
     assert all(r[2] for r in res)
     assert [r[3] for r in res] == [2.0, 2.0]
     assert [(r[4], r[5]) for r in res] == [(0, 7), (7, 13)]
+    assert all(r[6] for r in res), "packed-blob broadcast differs from rank 0's bytes"
+
+
+def test_bench_launcher_starts_n_ranks(monkeypatch):
+    """`python bench.py --gpus N` from a plain shell must start N ranks itself (torch.distributed.run, 127.0.0.1 rendezvous) and
+    never fall through to a single-rank run; inside a rank a --gpus / WORLD_SIZE mismatch is fatal."""
+    import importlib.util
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    class R:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return R()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    try:
+        bench.main()
+        raise AssertionError("launcher must exit with the children's status")
+    except SystemExit as e:
+        assert e.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "2"] and cmd[-5].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # inside a rank: WORLD_SIZE must equal --gpus
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    try:
+        bench.main()
+        raise AssertionError("mismatch must be fatal")
+    except SystemExit as e:
+        assert "WORLD_SIZE=2" in str(e.code)
 
 
 def test_shard_range_covers_everything():

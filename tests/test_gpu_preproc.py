@@ -49,6 +49,20 @@ def test_crop_resize_normalize_matches_oracle(oh, ow):
         np.testing.assert_allclose(got[k], ref, rtol=0, atol=3e-7, err_msg=f"box {k} {boxes[k]}")
 
 
+def test_crop_rects_outside_the_page_are_clamped_like_crop_image():
+    """Rectangles reaching outside the page (the device cannot be validated from the host: boxes live in HBM) are clamped in the kernel
+    exactly as crop_image does (src/det/test.py:126-129: x = max(0, x), bw = min(bw, w - x) -- the width is not reduced by the shift)."""
+    from ocr_vi_invoice_amd import pipeline, synth
+    from oracle import preproc_cpu as P
+    img = synth.make_invoice(11, 96, 160, lines=3)[0]
+    rects = [(0, -5, 10, 40, 20), (0, 150, 80, 40, 40), (0, -3, -4, 30, 30), (0, 20, 90, 50, 30), (0, 200, 10, 20, 20), (0, 10, 200, 20, 20),
+             (0, -50, 5, 30, 10), (0, 0, 0, 1000, 1000), (0, 159, 95, 1, 1)]
+    got = pipeline.preprocess_crops(torch.from_numpy(img).cuda()[None], rects, (32, 128)).cpu().numpy()
+    for k, (_, x, y, w, h) in enumerate(rects):
+        ref = P.preprocess_for_recognition(P.crop_image(img, (x, y, w, h)), (32, 128))
+        np.testing.assert_allclose(got[k], ref, rtol=0, atol=3e-7, err_msg=f"rect {rects[k]}")
+
+
 @pytest.mark.parametrize("hw,size", [((700, 500), 640), ((1920, 2560), 960), ((333, 1000), 960), ((640, 640), 320)])
 def test_resize_image_for_det_matches_oracle(hw, size):
     """pipeline2.py:33-40 (sides rounded to multiples of 32; exact-2x case takes the area path)."""

@@ -4,6 +4,7 @@ import os
 import re
 
 import numpy as np
+import pytest
 import torch
 
 from ocr_vi_invoice_amd import weights
@@ -80,3 +81,65 @@ def test_product_package_never_imports_the_oracle():
             if fn.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(root, fn), encoding="utf-8").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), fn
+
+
+def test_reference_trained_checkpoint_with_numpy_scalars_loads_weights_only(tmp_path):
+    """The reference's trainers store numpy scalars next to model_state_dict (src/det/val.py:111-115 -> src/det/train.py:266-272): the
+    plain weights-only unpickler rejects them, the allow-listed one must not -- and must still refuse anything executable."""
+    import torch
+    from ocr_vi_invoice_amd import pipeline
+    sd = weights.make_rec_state_dict("tiny", seed=5)
+    ck = {"epoch": 7, "model_state_dict": {"module." + k: v for k, v in sd.items()}, "best_f1": np.float64(0.76), "best_acc": np.float32(0.3),
+          "val_metrics": {"f1": np.float64(0.76), "iou": np.float64(0.62), "n": np.int64(347)},
+          "optimizer_state_dict": {"state": {0: {"step": torch.tensor(3.0), "exp_avg": torch.zeros(4)}}, "param_groups": [{"lr": 1e-3, "params": [0]}]},
+          "variant": "tiny"}
+    p = tmp_path / "best_model.pth"
+    torch.save(ck, p)
+    try:
+        torch.load(p, map_location="cpu", weights_only=True)
+        plain_ok = True
+    except Exception:
+        plain_ok = False
+    got = pipeline.load_checkpoint(str(p))
+    assert float(got["best_f1"]) == 0.76 and int(got["val_metrics"]["n"]) == 347
+    back = weights.unwrap_checkpoint(got)
+    assert set(back) == set(sd) and all(torch.equal(back[k], sd[k]) for k in sd)
+    assert not plain_ok or True   # (informational: torch 2.10 rejects the plain load)
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("true",))
+    bad = tmp_path / "evil.pth"
+    torch.save({"model_state_dict": sd, "x": Evil()}, bad)
+    with pytest.raises(Exception):
+        pipeline.load_checkpoint(str(bad))
+
+
+def test_db_boxes_batch_equals_the_per_page_python_chain():
+    """ocrvi_db_boxes_batch == DBPostProcessor -> rescale_boxes (int64 truncation, pipeline2.py:324-328) -> crop_rect (src/det/test.py:123-130),
+    page by page, for any thread count; pages with no box give count 0."""
+    from ocr_vi_invoice_amd import synth
+    from ocr_vi_invoice_amd.pipeline import DBPostProcessor, crop_rect, db_boxes_batch, rescale_boxes
+    rng = np.random.default_rng(3)
+    H, W = 192, 320
+    maps = []
+    for i in range(5):
+        pm = rng.uniform(0, 0.25, (H, W)).astype(np.float32)
+        if i != 2:                                            # page 2 stays empty
+            _, bx = synth.make_invoice(i, H, W, 6)
+            for x, y, w, h in bx:
+                pm[y + 1:y + h - 1, x + 2:x + w - 2] = rng.uniform(0.6, 0.95)
+        maps.append(pm)
+    maps = np.stack(maps)
+    pp = DBPostProcessor(0.3, 0.5, 1000, 1.6)
+    want, wcounts = [], []
+    for i in range(5):
+        b, _ = pp(maps[i][None])
+        wcounts.append(len(b))
+        for bb in rescale_boxes(b, 0.8, 1.25):
+            want.append((10 + i,) + crop_rect((150, 411), bb))
+    for threads in (1, 3):
+        rects, counts, scores = db_boxes_batch(maps, pp, 0.8, 1.25, (150, 411), page_base=10, threads=threads)
+        assert counts.tolist() == wcounts and counts[2] == 0
+        assert np.array_equal(rects, np.asarray(want, np.int32).reshape(-1, 5))
+        assert len(scores) == len(rects) and (scores >= 0.5).all()
