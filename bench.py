@@ -99,10 +99,35 @@ def cer(hyp, ref):
     return num / max(sum(len(r) for r in ref), 1)
 
 
-def shrink_box(x, y, w, h, ratio=0.4):
-    """DB's text-kernel shrink (the label rule behind the map the detector is trained to emit): offset D = A (1 - r^2) / L inwards."""
-    d = int(round(w * h * (1.0 - ratio * ratio) / (2.0 * (w + h))))
-    d = max(0, min(d, (min(w, h) - 3) // 2))
+def usable_cores(per_rank_cap=16):
+    """Host cores this process may really use: the affinity mask, cut by the cgroup CPU quota when there is one, and by the box's
+    per-GPU share (16).  os.cpu_count()/affinity alone can name every core of the host while the container is throttled to a few,
+    and an oversubscribed thread pool runs the CPU oracle tens of times slower."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, per_rank_cap))
+
+
+def shrink_box(x, y, w, h, unclip_ratio=1.6):
+    """Synthetic text kernel of a line box: the box shrunk by the offset d that the pipeline's unclip (distance = A * ratio / L of the
+    kernel, src/det/test.py:37-43 with pipeline2.py's ratio 1.6) maps back onto the line, i.e. the integer d minimising
+    |A_k * ratio / L_k - d| for the kernel (w - 2d) x (h - 2d).  (A trained DB head emits such kernels: its labels are the boxes
+    shrunk by A (1 - r^2) / L.)"""
+    best, best_err = 0, None
+    for d in range(0, max(1, (min(w, h) - 3) // 2 + 1)):
+        kw, kh = w - 2 * d, h - 2 * d
+        err = abs(kw * kh * unclip_ratio / (2.0 * (kw + kh)) - d)
+        if best_err is None or err < best_err:
+            best, best_err = d, err
+    d = best
     return x + d, y + d, w - 2 * d, h - 2 * d
 
 
@@ -120,11 +145,7 @@ class E2E:
         self.devi = torch.device(dev).index or 0
         # pipeline2.py:213-216,254-259 defaults: thresh 0.3, box_thresh 0.5, unclip 1.6, min_area 10
         self.pp = DBPostProcessor(thresh=0.3, box_thresh=0.5, max_candidates=1000, unclip_ratio=1.6)
-        try:
-            avail = len(os.sched_getaffinity(0))
-        except AttributeError:
-            avail = os.cpu_count() or 1
-        self.post_threads = args.post_threads or max(2, min(16, avail // max(n_ranks_on_host, 1)))
+        self.post_threads = args.post_threads or max(2, usable_cores(16))
         self.detected = args.boxes == "detected" and args.workload == "e2e"
 
     # ---- inputs
@@ -371,10 +392,7 @@ def cpu_baseline(args, det_sd, rec_sd, image_u8, crops_f32, gpu_texts):
     from ocr_vi_invoice_amd import synth
     from ocr_vi_invoice_amd.vocab import Tokenizer
     from oracle import dbnet_cpu, svtrv2_cpu
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
+    avail = usable_cores(16)
     torch.set_num_threads(avail)
     t_det = t_rec = 0.0
     sample = []
@@ -488,6 +506,9 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
 
+    if os.environ.get("OCRVI_BENCH_WATCHDOG"):   # development aid: dump every thread's stack if the run takes longer than N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["OCRVI_BENCH_WATCHDOG"]), repeat=True, file=sys.stderr)
     import numpy as np
     import torch
     rank = int(os.environ.get("RANK", "0"))

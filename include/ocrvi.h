@@ -166,6 +166,13 @@ int ocrvi_test_gemm(int device, int dtype, const float* a, const float* weight_h
 int ocrvi_test_attention(int device, int dtype, const float* qkv, int B, int N, int heads, float* out, int iters,
                          float* avg_ms);
 
+/* The fused MixingBlock MLP of the 16-bit modes (svtrv2.py:28-39,100): x [M][D] float32 DEVICE, updated in place to
+ * x + fc2(gelu(fc1(LayerNorm(x; ln_g, ln_b)))); with want_xn also xn_out [M][D] float32 DEVICE = LayerNorm(x_new; next_g, next_b) rounded to
+ * `dtype` (next_g == NULL: x_new rounded to `dtype`).  Weights and vectors are HOST float32 (fc1 [4D][D], fc2 [D][4D]).  D in {128, 256, 384}. */
+int ocrvi_test_mlp(int device, int dtype, float* x, const float* ln_g_host, const float* ln_b_host, const float* w1_host, const float* b1_host,
+                   const float* w2_host, const float* b2_host, const float* next_g_host, const float* next_b_host, int want_xn, int M, int D,
+                   float* xn_out, int iters, float* avg_ms);
+
 /* Per-launch HIP-event profiler (process-global, off by default).  While enabled every MFMA / bandwidth kernel launch
  * of the graphs above is bracketed by two events recorded on its launch stream.  ocrvi_prof_report synchronises those
  * events and writes a JSON object {tag: {launches, ms, flops, bytes}} (algorithmic FLOPs / bytes per tag) into buf. */

@@ -197,3 +197,39 @@ extern "C" int ocrvi_test_attention(int device, int dtype, const float* qkv, int
     OCRVI_HIP(hipStreamSynchronize(sc.s));
     return OCRVI_OK;
 }
+
+extern "C" int ocrvi_test_mlp(int device, int dtype, float* x, const float* ln_g_host, const float* ln_b_host, const float* w1_host, const float* b1_host,
+                              const float* w2_host, const float* b2_host, const float* next_g_host, const float* next_b_host, int want_xn, int M, int D,
+                              float* xn_out, int iters, float* avg_ms) {
+    OCRVI_CHECK(x && ln_g_host && ln_b_host && w1_host && b1_host && w2_host && b2_host && M > 0, OCRVI_EINVAL, "test_mlp: bad argument");
+    OCRVI_CHECK(mlp_fused_eligible(dtype, D), OCRVI_EINVAL, "test_mlp: the fused MLP needs a 16-bit dtype and D in {128, 256, 384} (got dtype %d, D %d)", dtype, D);
+    OCRVI_HIP(hipSetDevice(device));
+    Scratch sc;
+    OCRVI_TRY(sc.init());
+    DeviceStore st;
+    std::vector<char> packed;
+    pack_mlp_stream(w1_host, w2_host, D, dtype, packed);
+    void* ws = nullptr;
+    float *g = nullptr, *b = nullptr, *b1 = nullptr, *b2 = nullptr, *ng = nullptr, *nb = nullptr;
+    OCRVI_TRY(st.upload(packed.data(), packed.size(), &ws));
+    OCRVI_TRY(st.upload(ln_g_host, (size_t)D * 4, (void**)&g));
+    OCRVI_TRY(st.upload(ln_b_host, (size_t)D * 4, (void**)&b));
+    OCRVI_TRY(st.upload(b1_host, (size_t)4 * D * 4, (void**)&b1));
+    OCRVI_TRY(st.upload(b2_host, (size_t)D * 4, (void**)&b2));
+    if (next_g_host) {
+        OCRVI_TRY(st.upload(next_g_host, (size_t)D * 4, (void**)&ng));
+        OCRVI_TRY(st.upload(next_b_host, (size_t)D * 4, (void**)&nb));
+    }
+    void *xn = nullptr, *x0 = nullptr;
+    if (want_xn) OCRVI_TRY(sc.alloc((size_t)M * D * dtype_size(dtype), &xn));
+    OCRVI_TRY(sc.alloc((size_t)M * D * 4, &x0));   // the kernel updates x in place: every timed repeat starts from the caller's x
+    OCRVI_HIP(hipMemcpyAsync(x0, x, (size_t)M * D * 4, hipMemcpyDeviceToDevice, sc.s));
+    OCRVI_TRY(timed(sc, iters, avg_ms, [&]() {
+        return k_mlp_fused(dtype, (float*)x0, xn, g, b, ng, nb, ws, b1, b2, M, D, sc.s);
+    }));
+    // one clean application for the result
+    OCRVI_TRY(k_mlp_fused(dtype, x, xn, g, b, ng, nb, ws, b1, b2, M, D, sc.s));
+    if (want_xn && xn_out) OCRVI_TRY(k_nhwc_to_nchw_f32(dtype, xn, xn_out, 1, 1, M * D, 1, 1, 0, sc.s));
+    OCRVI_HIP(hipStreamSynchronize(sc.s));
+    return OCRVI_OK;
+}

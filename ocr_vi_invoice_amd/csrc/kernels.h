@@ -12,6 +12,13 @@ int k_maxpool3x3s2(int dtype, const void* x, void* y, int N, int H, int W, int C
 // LayerNorm over the last dim (eps 1e-5, svtrv2.py:93,95,446).  x is f32 or T, out is f32 or T.
 int k_layernorm(int dtype, const void* x, int x_f32, void* out, int out_f32, const float* gamma, const float* beta, int rows, int D,
                 hipStream_t s);
+// Fused MixingBlock MLP for the 16-bit modes (mlp_fused.hip):  x <- x + fc2(gelu(fc1(LN(x; ln_g, ln_b))))  in place on the fp32
+// residual stream x [M][D]; when xn != null also writes xn [M][D] T = LN(x_new; next_g, next_b), or T(x_new) when next_g == null.
+// wstream = pack_mlp_stream(fc1.weight [4D][D], fc2.weight [D][4D]) uploaded to the device; b1 [4D], b2 [D] device fp32.
+bool mlp_fused_eligible(int dtype, int D);
+void pack_mlp_stream(const float* w1, const float* w2, int D, int dtype, std::vector<char>& out);
+int k_mlp_fused(int dtype, float* x, void* xn, const float* ln_g, const float* ln_b, const float* next_g, const float* next_b, const void* wstream,
+                const float* b1, const float* b2, int M, int D, hipStream_t s);
 // f32 -> T cast (n elements).
 int k_cast_from_f32(int dtype, const float* x, void* y, size_t n, hipStream_t s);
 // T NHWC [N,H,W,C] (row stride ld, channel offset coff) -> float32 NCHW (test taps / API outputs).

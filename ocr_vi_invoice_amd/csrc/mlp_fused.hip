@@ -1,0 +1,350 @@
+// Fused MixingBlock MLP for the 16-bit modes (svtrv2.py:28-39,100):   x <- x + fc2(gelu(fc1(LayerNorm(x))))   [+ the NEXT LayerNorm]
+//
+// Unfused, the 4*D hidden activation makes a round trip through HBM (189 MB per 256 crops at D = 384) and LayerNorm is a kernel of
+// its own; the two GEMMs are then bound by the latency of their operand streams.  Here one workgroup owns 128
+// tokens for the whole block:
+//   * the tokens' LayerNorm'ed activations are built once, in REGISTERS, as MFMA B-operand fragments (fp32 x -> statistics over the
+//     4 lanes that share a token -> 16-bit), D/4 VGPRs per lane;
+//   * the hidden dimension is walked in chunks of 64: GEMM1 (64 x D slice of fc1) -> bias + exact GELU in registers -> the fp32
+//     accumulators become, 16-bit packed, the B operand of GEMM2 (D x 64 slice of fc2) with no LDS round trip: an accumulator lane
+//     holds 4 consecutive hidden units of one token, and fc2's columns are permuted at pack time so that those are exactly the
+//     k-slots the lane owns in the next MFMA (cdna_hip_programming.md section 3, "An accumulator tile as the next MFMA's operand");
+//   * fc2 accumulates all D outputs of the 32 tokens of a wave in registers (D/2 VGPRs, one wave per SIMD owns the 512-entry file);
+//   * the only streamed operand is the weights, identical for every tile: they are packed at load time into 16-KiB "pieces" in LDS
+//     image order and DMA'd (global_load_lds_dwordx4) into a ring that runs ahead across chunk and tile boundaries, counted vmcnt,
+//     one barrier per piece (the gemm_ring protocol with a deeper ring);
+//   * epilogue: + bias + fp32 residual -> x; optionally LayerNorm of the result with the NEXT block's norm1 (or a plain cast) -> xn,
+//     which removes that LayerNorm / cast kernel too.
+// Per token tile the CU streams 4*D/64 * 256*D bytes of weights from L2 (2.36 MB at D = 384) for 2*128*8*D*D FLOP: 131 FLOP/B.
+#include <string.h>
+
+#include "gemm_ring.h"
+#include "kernels.h"
+
+namespace ocrvi {
+
+struct MlpParams {
+    float* x = nullptr;            // [M][D] fp32 residual stream, updated in place
+    void* xn = nullptr;            // optional [M][D] T: LayerNorm_next(x_new) (next_g != null) or T(x_new) (next_g == null)
+    const float* ln_g = nullptr;   // norm2 of this block
+    const float* ln_b = nullptr;
+    const float* next_g = nullptr;
+    const float* next_b = nullptr;
+    const void* wstream = nullptr; // packed pieces (pack_mlp_stream)
+    const float* b1 = nullptr;     // [4D]
+    const float* b2 = nullptr;     // [D]
+    int M = 0;
+};
+
+constexpr int kPiece = 16384;
+
+template <typename T> __device__ __forceinline__ uint32_t pack2(float a, float b) {
+    union { T h[2]; uint32_t u; } r;
+    r.h[0] = (T)a; r.h[1] = (T)b;
+    return r.u;
+}
+
+template <typename T, int D, int WPS, int R>
+__global__ __launch_bounds__(256, WPS) void mlp_fused_kernel(const MlpParams p) {
+    constexpr int KS = D / 64;         // 128-byte K-steps of GEMM1
+    constexpr int NP = D / 128;        // pieces per chunk and GEMM (W1: 2 K-steps x 64 rows; W2: 128 rows x 1 K-step)
+    constexpr int NCH = 4 * D / 64;    // hidden chunks of 64
+    constexpr int PPT = NCH * 2 * NP;  // pieces per token tile
+    constexpr int PF = R - 1;          // pieces in flight
+    constexpr int NB2 = D / 16;        // 16-channel output blocks
+    static_assert(D % 128 == 0 && D <= 384, "D");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    float* const c_b1 = (float*)(smem + R * kPiece);   // [4D]
+    float* const c_b2 = c_b1 + 4 * D;                  // [D]
+    float* const c_g = c_b2 + D;                       // norm2 gamma, beta, next gamma, beta: [D] each
+    float* const c_be = c_g + D;
+    float* const c_ng = c_be + D;
+    float* const c_nb = c_ng + D;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, g = lane >> 4;
+    const bool next_ln = p.next_g != nullptr;
+    for (int i = tid; i < 4 * D; i += 256) c_b1[i] = p.b1[i];
+    for (int i = tid; i < D; i += 256) {
+        c_b2[i] = p.b2[i];
+        c_g[i] = p.ln_g[i];
+        c_be[i] = p.ln_b[i];
+        c_ng[i] = next_ln ? p.next_g[i] : 1.f;
+        c_nb[i] = next_ln ? p.next_b[i] : 0.f;
+    }
+    __syncthreads();  // (also drains those loads: no VMEM op is in flight when the ring starts)
+
+    const int ntiles = (p.M + 127) >> 7;
+    const int G = gridDim.x;
+    const int my_tiles = (ntiles - (int)blockIdx.x + G - 1) / G;
+    const int total = my_tiles * PPT;  // pieces this workgroup consumes
+
+    // ---- weight ring: piece q of the stream is piece (q % PPT) of the packed buffer; this wave issues DMA instructions wave, wave + 4,
+    // wave + 8, wave + 12 of its 16 (8 row-slots x 128 B each); the XOR swizzle is applied on the source chunk (rule 21)
+    const int prow = lane >> 3;
+    const unsigned voff = (unsigned)((8 * wave + prow) * 128 + (((lane & 7) ^ swz128(8 * wave + prow)) << 4));
+    const char* const wbase = uniform_ptr((const char*)p.wstream);
+    int prod = 0, prod_mod = 0;
+    auto issue_piece = [&]() {
+        const char* src = wbase + (size_t)prod_mod * kPiece;
+        const unsigned dst = lds0 + (prod % R) * kPiece + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(src + j * 4096, voff, __builtin_amdgcn_readfirstlane(dst + j * 4096));
+        ++prod;
+        if (++prod_mod == PPT) prod_mod = 0;
+    };
+    int cons = 0;
+    auto next_piece = [&]() -> const char* {  // wait for piece `cons`, free the slot of piece cons - 1, keep the ring full
+        if (total - 1 - cons >= PF - 1) wait_vm_barrier<(PF - 1) * 4>(); else wait_vm_barrier<0>();
+        if (prod < total) issue_piece();
+        const char* s = smem + (cons % R) * kPiece;
+        ++cons;
+        return s;
+    };
+    for (int i = 0; i < PF && i < total; ++i) issue_piece();
+
+    const int swa = swz128(lr);
+    const int fo0 = ((2 * g) ^ swa) << 4, fo1 = ((2 * g + 1) ^ swa) << 4;
+
+    for (int t = 0; t < my_tiles; ++t) {
+        const int tile = (int)blockIdx.x + t * G;
+        const int tok0 = tile * 128 + wave * 32;
+        // ---- prologue: LayerNorm(x) of this wave's 32 tokens -> B-operand fragments.  Lane (lr, g) of token block b owns channels
+        // 64 ks + 16 g .. + 16 of token tok0 + 16 b + lr for every K-step ks: its two 8-element halves are the two MFMA k-slots.
+        uint4 xf[KS][2][2];  // [ks][half][token block]
+        {
+            float xv[2][KS][16];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int tok = min(tok0 + 16 * b + lr, p.M - 1);
+                const float* xr = p.x + (size_t)tok * D + 16 * g;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 v = *(const float4*)(xr + 64 * ks + 4 * q);
+                        xv[b][ks][4 * q] = v.x; xv[b][ks][4 * q + 1] = v.y; xv[b][ks][4 * q + 2] = v.z; xv[b][ks][4 * q + 3] = v.w;
+                    }
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                float sum = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) sum += xv[b][ks][e];
+                sum += __shfl_xor(sum, 16);
+                sum += __shfl_xor(sum, 32);
+                const float mean = sum / (float)D;
+                float sq = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) { const float d = xv[b][ks][e] - mean; sq += d * d; }
+                sq += __shfl_xor(sq, 16);
+                sq += __shfl_xor(sq, 32);
+                const float rstd = rsqrtf(sq / (float)D + 1e-5f);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    float o[16];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 gv = *(const float4*)(c_g + 64 * ks + 16 * g + 4 * q), bv = *(const float4*)(c_be + 64 * ks + 16 * g + 4 * q);
+                        o[4 * q] = (xv[b][ks][4 * q] - mean) * rstd * gv.x + bv.x;
+                        o[4 * q + 1] = (xv[b][ks][4 * q + 1] - mean) * rstd * gv.y + bv.y;
+                        o[4 * q + 2] = (xv[b][ks][4 * q + 2] - mean) * rstd * gv.z + bv.z;
+                        o[4 * q + 3] = (xv[b][ks][4 * q + 3] - mean) * rstd * gv.w + bv.w;
+                    }
+                    xf[ks][0][b] = make_uint4(pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]), pack2<T>(o[4], o[5]), pack2<T>(o[6], o[7]));
+                    xf[ks][1][b] = make_uint4(pack2<T>(o[8], o[9]), pack2<T>(o[10], o[11]), pack2<T>(o[12], o[13]), pack2<T>(o[14], o[15]));
+                }
+            }
+        }
+        // every VMEM op issued so far (ring DMAs, the previous tile's stores, the loads above) has completed: the counted waits of
+        // the main loop start from an empty queue
+        wait_vm_only<0>();
+
+        f32x4 acc2[NB2][2];
+#pragma unroll
+        for (int a = 0; a < NB2; ++a) {
+            acc2[a][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc2[a][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        for (int hc = 0; hc < NCH; ++hc) {
+            // ---- GEMM1: hidden chunk [64 hc, +64) of fc1 for this wave's 32 tokens
+            f32x4 acc1[4][2];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                acc1[a][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                acc1[a][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int p1 = 0; p1 < NP; ++p1) {
+                const char* S = next_piece();
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int fo = h == 0 ? fo0 : fo1;
+                        uint4 wf[4];
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) wf[a] = *(const uint4*)(S + (kk * 64 + a * 16 + lr) * 128 + fo);
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) {
+                            Mma<T>::half(wf[a], xf[2 * p1 + kk][h][0], acc1[a][0]);
+                            Mma<T>::half(wf[a], xf[2 * p1 + kk][h][1], acc1[a][1]);
+                        }
+                    }
+            }
+            // ---- bias + exact GELU; the lane's 16 hidden units per token become its two k-slot halves of GEMM2:
+            // half h', element j  <->  hidden 16 (2 h' + (j >> 2)) + 4 g + (j & 3)   (fc2's columns are packed in that order)
+            uint4 hf[2][2];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const float4 bA = *(const float4*)(c_b1 + 64 * hc + 16 * (2 * hh) + 4 * g), bB = *(const float4*)(c_b1 + 64 * hc + 16 * (2 * hh + 1) + 4 * g);
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const f32x4 u = acc1[2 * hh][b], v = acc1[2 * hh + 1][b];
+                    hf[hh][b] = make_uint4(pack2<T>(gelu_erf(u[0] + bA.x), gelu_erf(u[1] + bA.y)), pack2<T>(gelu_erf(u[2] + bA.z), gelu_erf(u[3] + bA.w)),
+                                           pack2<T>(gelu_erf(v[0] + bB.x), gelu_erf(v[1] + bB.y)), pack2<T>(gelu_erf(v[2] + bB.z), gelu_erf(v[3] + bB.w)));
+                }
+            }
+            // ---- GEMM2: all D outputs += fc2[:, chunk] . h
+#pragma unroll
+            for (int p2 = 0; p2 < NP; ++p2) {
+                const char* S = next_piece();
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int fo = h == 0 ? fo0 : fo1;
+#pragma unroll
+                    for (int a4 = 0; a4 < 8; a4 += 4) {
+                        uint4 wf[4];
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) wf[a] = *(const uint4*)(S + ((a4 + a) * 16 + lr) * 128 + fo);
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) {
+                            Mma<T>::half(wf[a], hf[h][0], acc2[p2 * 8 + a4 + a][0]);
+                            Mma<T>::half(wf[a], hf[h][1], acc2[p2 * 8 + a4 + a][1]);
+                        }
+                    }
+                }
+            }
+        }
+        // ---- epilogue: x <- x + fc2(..) + b2 (lane: channels 16 a + 4 g .. + 4 of token tok0 + 16 b + lr), then the optional next norm
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int tok = tok0 + 16 * b + lr;
+            const bool ok = tok < p.M;
+            float* xr = p.x + (size_t)(ok ? tok : 0) * D + 4 * g;
+            float sum = 0.f;
+#pragma unroll
+            for (int a = 0; a < NB2; ++a) {
+                const float4 bv = *(const float4*)(c_b2 + 16 * a + 4 * g);
+                float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok) rv = *(const float4*)(xr + 16 * a);
+                f32x4 v = acc2[a][b];
+                v[0] += bv.x + rv.x; v[1] += bv.y + rv.y; v[2] += bv.z + rv.z; v[3] += bv.w + rv.w;
+                acc2[a][b] = v;
+                if (ok) *(float4*)(xr + 16 * a) = make_float4(v[0], v[1], v[2], v[3]);
+                sum += v[0] + v[1] + v[2] + v[3];
+            }
+            if (p.xn) {
+                float mean = 0.f, rstd = 1.f;
+                if (next_ln) {
+                    sum += __shfl_xor(sum, 16);
+                    sum += __shfl_xor(sum, 32);
+                    mean = sum / (float)D;
+                    float sq = 0.f;
+#pragma unroll
+                    for (int a = 0; a < NB2; ++a)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { const float d = acc2[a][b][r] - mean; sq += d * d; }
+                    sq += __shfl_xor(sq, 16);
+                    sq += __shfl_xor(sq, 32);
+                    rstd = rsqrtf(sq / (float)D + 1e-5f);
+                }
+                T* nr = (T*)p.xn + (size_t)(ok ? tok : 0) * D + 4 * g;
+#pragma unroll
+                for (int a = 0; a < NB2; ++a) {
+                    const float4 gv = *(const float4*)(c_ng + 16 * a + 4 * g), bv = *(const float4*)(c_nb + 16 * a + 4 * g);
+                    const f32x4 v = acc2[a][b];
+                    uint2 o;
+                    o.x = pack2<T>((v[0] - mean) * rstd * gv.x + bv.x, (v[1] - mean) * rstd * gv.y + bv.y);
+                    o.y = pack2<T>((v[2] - mean) * rstd * gv.z + bv.z, (v[3] - mean) * rstd * gv.w + bv.w);
+                    if (ok) *(uint2*)(nr + 16 * a) = o;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- host: packing + launch
+// Stream order: for each hidden chunk hc: NP W1 pieces (piece p1 = K-steps 2 p1 and 2 p1 + 1, each 64 rows [hidden 64 hc + r] x 64
+// elements of K), then NP W2 pieces (piece p2 = output rows 128 p2 .. + 128, each 64 elements = hidden chunk hc in the k-slot order
+// the accumulator lanes produce: position 16 g + 8 h + j  <->  hidden 16 (2 h + (j >> 2)) + 4 g + (j & 3)).
+void pack_mlp_stream(const float* w1, const float* w2, int D, int dtype, std::vector<char>& out) {
+    const int H4 = 4 * D, NCH = H4 / 64, NP = D / 128;
+    const size_t esz = dtype_size(dtype);
+    std::vector<float> buf((size_t)NCH * 2 * NP * (kPiece / esz));
+    size_t o = 0;
+    for (int hc = 0; hc < NCH; ++hc) {
+        for (int p1 = 0; p1 < NP; ++p1)
+            for (int kk = 0; kk < 2; ++kk)
+                for (int r = 0; r < 64; ++r)
+                    for (int e = 0; e < 64; ++e) buf[o++] = w1[(size_t)(64 * hc + r) * D + 64 * (2 * p1 + kk) + e];
+        for (int p2 = 0; p2 < NP; ++p2)
+            for (int n = 0; n < 128; ++n)
+                for (int pos = 0; pos < 64; ++pos) {
+                    const int g = pos >> 4, h = (pos >> 3) & 1, j = pos & 7;
+                    const int hid = 16 * (2 * h + (j >> 2)) + 4 * g + (j & 3);
+                    buf[o++] = w2[(size_t)(128 * p2 + n) * H4 + 64 * hc + hid];
+                }
+    }
+    out.resize(buf.size() * esz);
+    convert_to_dtype(buf.data(), buf.size(), dtype, out.data());
+}
+
+bool mlp_fused_eligible(int dtype, int D) { return dtype != OCRVI_F32 && D % 128 == 0 && D >= 128 && D <= 384; }
+
+template <typename T, int D, int WPS, int R>
+static int launch_mlp(const MlpParams& p, hipStream_t s) {
+    const int smem = R * kPiece + (4 * D + 5 * D) * 4;
+    auto kern = mlp_fused_kernel<T, D, WPS, R>;
+    OCRVI_TRY(ensure_max_smem((const void*)kern, smem));
+    int n_cu = 0;
+    OCRVI_TRY(device_cus(&n_cu));
+    const int ntiles = (p.M + 127) / 128;
+    int grid = std::min(ntiles, n_cu * WPS);
+    grid = cdiv(ntiles, cdiv(ntiles, grid));  // equal tile counts
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, p);
+    OCRVI_HIP(hipGetLastError());
+    return OCRVI_OK;
+}
+
+template <typename T> static int mlp_dt(const MlpParams& p, int D, hipStream_t s) {
+    switch (D) {
+        case 128: return launch_mlp<T, 128, 2, 4>(p, s);   // 2 workgroups per CU (256 VGPRs each), 64-KiB ring
+        case 256: return launch_mlp<T, 256, 1, 9>(p, s);
+        case 384: return launch_mlp<T, 384, 1, 9>(p, s);
+    }
+    set_error("mlp_fused: D=%d unsupported", D);
+    return OCRVI_EINVAL;
+}
+
+int k_mlp_fused(int dtype, float* x, void* xn, const float* ln_g, const float* ln_b, const float* next_g, const float* next_b, const void* wstream,
+                const float* b1, const float* b2, int M, int D, hipStream_t s) {
+    OCRVI_CHECK(mlp_fused_eligible(dtype, D) && x && ln_g && ln_b && wstream && b1 && b2 && M > 0 && M < (1 << 24), OCRVI_EINVAL,
+                "mlp_fused: bad argument (dtype %d, D %d, M %d)", dtype, D, M);
+    MlpParams p;
+    p.x = x; p.xn = xn; p.ln_g = ln_g; p.ln_b = ln_b; p.next_g = next_g; p.next_b = next_b; p.wstream = wstream; p.b1 = b1; p.b2 = b2; p.M = M;
+    char tag[64];
+    snprintf(tag, sizeof(tag), "mlp_fused_d%d_%s", D, dtype_name(dtype));
+    const double esz = (double)dtype_size(dtype);
+    ProfScope ps(tag, 2.0 * M * 8.0 * D * D, (double)M * D * (8.0 + (xn ? esz : 0.0)) + 8.0 * D * D * esz, s);
+    if (dtype == OCRVI_BF16) return mlp_dt<bf16_t>(p, D, s);
+    return mlp_dt<f16_t>(p, D, s);
+}
+
+}  // namespace ocrvi

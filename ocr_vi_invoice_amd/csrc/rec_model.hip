@@ -1,5 +1,6 @@
 // SVTRv2 inference graph (model/rec2/svtrv2.py:475-536) + device half of greedy CTC decode (:555-566).
 // The residual stream is kept in fp32; GEMM operands are the handle's compute dtype.
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -12,7 +13,11 @@ using namespace ocrvi;
 
 namespace {
 struct LNw { float *g = nullptr, *b = nullptr; };
-struct MlpW { ConvLayer fc1, fc2; };
+struct MlpW {
+    ConvLayer fc1, fc2;
+    void* stream = nullptr;      // 16-bit modes, D % 128 == 0: fc1 / fc2 packed for the fused MLP kernel (mlp_fused.hip)
+    float *b1 = nullptr, *b2 = nullptr;
+};
 struct BlockW {
     bool local = false;
     LNw n1, n2;
@@ -47,7 +52,21 @@ static int load_lin(DeviceStore& st, const Blob& b, const std::string& name, int
 }
 static int load_mlp(DeviceStore& st, const Blob& b, const std::string& name, int d, int dt, MlpW* m) {
     OCRVI_TRY(load_lin(st, b, name + ".fc1", 4 * d, d, dt, &m->fc1));
-    return load_lin(st, b, name + ".fc2", d, 4 * d, dt, &m->fc2);
+    OCRVI_TRY(load_lin(st, b, name + ".fc2", d, 4 * d, dt, &m->fc2));
+    static const bool fuse = !(getenv("OCRVI_MLP_FUSED") && atoi(getenv("OCRVI_MLP_FUSED")) == 0);   // A/B switch
+    if (fuse && mlp_fused_eligible(dt, d)) {
+        const BlobTensor *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr;
+        OCRVI_TRY(b.get(name + ".fc1.w", 4 * d, d, 0, 0, &w1));
+        OCRVI_TRY(b.get(name + ".fc1.b", 4 * d, 0, 0, 0, &b1));
+        OCRVI_TRY(b.get(name + ".fc2.w", d, 4 * d, 0, 0, &w2));
+        OCRVI_TRY(b.get(name + ".fc2.b", d, 0, 0, 0, &b2));
+        std::vector<char> packed;
+        pack_mlp_stream(w1->data, w2->data, d, dt, packed);
+        OCRVI_TRY(st.upload(packed.data(), packed.size(), &m->stream));
+        OCRVI_TRY(st.upload(b1->data, (size_t)4 * d * 4, (void**)&m->b1));
+        OCRVI_TRY(st.upload(b2->data, (size_t)d * 4, (void**)&m->b2));
+    }
+    return OCRVI_OK;
 }
 
 extern "C" int ocrvi_rec_create(int device, const void* blob_p, size_t blob_bytes, const ocrvi_rec_cfg* cfg, ocrvi_rec** out) {
@@ -142,9 +161,19 @@ static Tensor view(const Tensor& t, int n, int h, int w, int c) {
     return v;
 }
 
-// y = x + fc2(gelu(fc1(LN(x))))   (svtrv2.py:38-39,100)
-static int mlp_block(Runner& r, const Tensor& x, const Tensor& xn, const Tensor& hb, const LNw& n, const MlpW& m, int d) {
+// y = x + fc2(gelu(fc1(LN(x))))   (svtrv2.py:38-39,100).  `next`: what the caller needs in xn afterwards -- nullptr: nothing; a norm:
+// LN(y) with it; &kCast: T(y).  Returns through *xn_done whether xn was produced (the fused kernel does it in its epilogue).
+static const LNw kCast{};
+static int mlp_block(Runner& r, const Tensor& x, const Tensor& xn, const Tensor& hb, const LNw& n, const MlpW& m, int d, const LNw* next = nullptr,
+                     bool* xn_done = nullptr) {
     const int rows = (int)x.pixels();
+    if (xn_done) *xn_done = false;
+    if (m.stream) {
+        if (xn_done) *xn_done = next != nullptr;
+        if (r.dry()) return OCRVI_OK;
+        return k_mlp_fused(r.dtype, (float*)x.p, next ? xn.p : nullptr, n.g, n.b, next ? next->g : nullptr, next ? next->b : nullptr, m.stream, m.b1, m.b2,
+                           rows, d, r.stream);
+    }
     OCRVI_TRY(ln(r, x, xn, n));
     ConvOpts o1;
     o1.act = ACT_GELU;
@@ -204,8 +233,11 @@ static int rec_run(ocrvi_rec* h, Runner& r, const float* x, int B, int H, int W,
         Tensor xn; xn.p = XN; xn.n = B; xn.h = Hs; xn.w = Ws; xn.c = d; xn.f32 = false;
         Tensor t1 = xn; t1.p = T1;
         Tensor big; big.p = BIG; big.n = rows; big.h = big.w = 1; big.c = 4 * d; big.f32 = false;
-        for (const BlockW& bw : h->blocks[s]) {
-            OCRVI_TRY(ln(r, xs, xn, bw.n1));
+        bool xn_ready = false;   // the previous block's fused MLP already wrote LN(x; norm1) (or the cast the merge needs) into xn
+        const int nblk = (int)h->blocks[s].size();
+        for (int bi = 0; bi < nblk; ++bi) {
+            const BlockW& bw = h->blocks[s][bi];
+            if (!xn_ready) OCRVI_TRY(ln(r, xs, xn, bw.n1));
             if (bw.local) {  // x + gelu(bn(conv(gelu(bn(conv(LN x))))))  (svtrv2.py:57-63,98)
                 ConvOpts o;
                 o.pad = 1; o.act = ACT_GELU;
@@ -219,12 +251,13 @@ static int rec_run(ocrvi_rec* h, Runner& r, const float* x, int B, int H, int W,
                 o.res = &xs; o.res_mode = RES_SAME;
                 OCRVI_TRY(conv(r, bw.proj, view(t1, rows, 1, 1, d), view(xs, rows, 1, 1, d), o));
             }
-            OCRVI_TRY(mlp_block(r, view(xs, rows, 1, 1, d), xn, big, bw.n2, bw.mlp, d));
+            const LNw* next = bi + 1 < nblk ? &h->blocks[s][bi + 1].n1 : ((s < 2 && lowp) ? &kCast : nullptr);
+            OCRVI_TRY(mlp_block(r, view(xs, rows, 1, 1, d), xn, big, bw.n2, bw.mlp, d, next, &xn_ready));
         }
         if (s < 2) {  // PatchMerging (svtrv2.py:131-138): conv3x3 stride (2,1) + BN, no activation
             Tensor src = xn;
             if (lowp) {
-                if (!r.dry()) OCRVI_TRY(k_cast_from_f32(dt, (const float*)xs.p, xn.p, (size_t)rows * d, r.stream));
+                if (!xn_ready && !r.dry()) OCRVI_TRY(k_cast_from_f32(dt, (const float*)xs.p, xn.p, (size_t)rows * d, r.stream));
             } else {
                 src = xs; src.f32 = false;
             }
@@ -255,8 +288,9 @@ static int rec_run(ocrvi_rec* h, Runner& r, const float* x, int B, int H, int W,
         o.res = &bn; o.res_mode = RES_SAME;
         OCRVI_TRY(conv(r, h->h_proj, t1, xr, o));
     }
-    OCRVI_TRY(mlp_block(r, xr, xn, big, h->h_norm2, h->h_mlp, d2));
-    OCRVI_TRY(ln(r, xr, xn, h->v_norm_kv));
+    bool xn_ready = false;
+    OCRVI_TRY(mlp_block(r, xr, xn, big, h->h_norm2, h->h_mlp, d2, &h->v_norm_kv, &xn_ready));
+    if (!xn_ready) OCRVI_TRY(ln(r, xr, xn, h->v_norm_kv));
     const int cols = B * Ws;
     Tensor tq; tq.p = bn.p; tq.n = cols; tq.h = tq.w = 1; tq.c = d2; tq.f32 = true;
     // note: tq would alias the backbone_norm tap; use a fresh buffer so the tap survives
@@ -267,12 +301,12 @@ static int rec_run(ocrvi_rec* h, Runner& r, const float* x, int B, int H, int W,
         if (!r.dry()) OCRVI_TRY(k_frm_vertical(dt, big.p, h->vq, t1.p, B, Hs, Ws, d2, r.stream));
         OCRVI_TRY(conv(r, h->v_proj, view(t1, cols, 1, 1, d2), tq, o));  // bias carries + select_token
     }
-    OCRVI_TRY(mlp_block(r, tq, view(xn, cols, 1, 1, d2), big, h->v_norm2, h->v_mlp, d2));
+    OCRVI_TRY(mlp_block(r, tq, view(xn, cols, 1, 1, d2), big, h->v_norm2, h->v_mlp, d2, lowp ? &kCast : nullptr, &xn_ready));
     h->tap_frm = tq.p;
     // ---- CTC head (svtrv2.py:528-532) + greedy decode (svtrv2.py:555-566)
     Tensor hin = view(xn, cols, 1, 1, d2);
     if (lowp) {
-        if (!r.dry()) OCRVI_TRY(k_cast_from_f32(dt, (const float*)tq.p, xn.p, (size_t)cols * d2, r.stream));
+        if (!xn_ready && !r.dry()) OCRVI_TRY(k_cast_from_f32(dt, (const float*)tq.p, xn.p, (size_t)cols * d2, r.stream));
     } else {
         hin = tq; hin.f32 = false;
     }

@@ -61,9 +61,10 @@ def test_rec_bf16_tracks_fp32_parity_mode_on_a_subbatch():
     from ocr_vi_invoice_amd import SVTRv2, synth
     x = torch.from_numpy(synth.pad_crop_batch(synth.make_crops(9, 32, 48, 320), 48, 320)).cuda()
     ref = SVTRv2("base", dtype="f32", seed=1234)(x)
-    for dt, tol in (("bf16", 0.5), ("f16", 0.06)):
+    # budgets = 1.5 x the values measured on MI355X in round 2 (bf16 0.1409 / 0.9969, f16 0.0211 / 0.9996)
+    for dt, tol, min_agree in (("bf16", 0.21, 0.993), ("f16", 0.032, 0.999)):
         lp = SVTRv2("base", dtype=dt, seed=1234)(x)
         err = float((lp - ref).abs().max())
         agree = float((lp.argmax(-1) == ref.argmax(-1)).float().mean())
         print(f"\n[{dt}] vs f32: max-abs-err {err:.4f}, argmax agreement {agree:.4f}")
-        assert err < tol and agree > 0.97
+        assert err < tol and agree > min_agree

@@ -251,3 +251,39 @@ def test_attention_rejects_long_sequences():
     out = torch.empty(1, 600, 32, device="cuda")
     with pytest.raises(ValueError):
         L.check(L.load().ocrvi_test_attention(0, 1, qkv.data_ptr(), 1, 600, 1, out.data_ptr(), 0, None))
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("M,D,mode", [(128, 128, "ln"), (1000, 128, "cast"), (333, 256, "ln"), (40, 256, "none"), (2048 + 77, 384, "ln"),
+                                      (129, 384, "cast")])
+def test_mlp_fused_kernel(M, D, mode, dt):
+    """x + fc2(gelu(fc1(LN(x)))) (svtrv2.py:28-39,100) and the fused next LayerNorm / cast, against torch fp64 -> fp32; ragged M (tail tile,
+    several tiles per workgroup at M > 128 * #CU is covered by the model tests); twice, bit-identical."""
+    L = _lib()
+    lib = L.load()
+    g = torch.Generator().manual_seed(M + D)
+    x = torch.randn(M, D, generator=g) * 1.5 + 0.3
+    lg, lb = torch.rand(D, generator=g) * 0.4 + 0.8, torch.randn(D, generator=g) * 0.05
+    w1, b1 = torch.randn(4 * D, D, generator=g) * np.sqrt(2.0 / D), torch.randn(4 * D, generator=g) * 0.02
+    w2, b2 = torch.randn(D, 4 * D, generator=g) * np.sqrt(0.5 / (4 * D)), torch.randn(D, generator=g) * 0.02
+    ng, nb = torch.rand(D, generator=g) * 0.4 + 0.8, torch.randn(D, generator=g) * 0.05
+    xd = x.double()
+    y = xd + F.gelu(F.layer_norm(xd, (D,), lg.double(), lb.double(), 1e-5) @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double()
+    want_xn = {"ln": F.layer_norm(y, (D,), ng.double(), nb.double(), 1e-5), "cast": y, "none": None}[mode]
+    h = lambda t: np.ascontiguousarray(t.numpy(), dtype=np.float32)
+    arrs = [h(lg), h(lb), h(w1), h(b1), h(w2), h(b2), h(ng), h(nb)]
+    outs = []
+    for _ in range(2):
+        xdev = x.cuda().clone()
+        xn = torch.zeros((M, D), device="cuda")
+        ms = C.c_float(0)
+        L.check(lib.ocrvi_test_mlp(0, DT[dt], xdev.data_ptr(), *[a.ctypes.data for a in arrs[:6]],
+                                   arrs[6].ctypes.data if mode == "ln" else None, arrs[7].ctypes.data if mode == "ln" else None,
+                                   0 if mode == "none" else 1, M, D, xn.data_ptr(), 0, C.byref(ms)))
+        outs.append((xdev.cpu(), xn.cpu()))
+    # the MLP branch is what carries the 16-bit error; the residual stream itself stays fp32
+    err = float((outs[0][0].double() - y).abs().max() / ((y - xd).pow(2).mean().sqrt() + 1e-12))
+    assert err < TOL[dt], err
+    if want_xn is not None:
+        assert _rel_err(outs[0][1], want_xn.float()) < 1.5 * TOL[dt]
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

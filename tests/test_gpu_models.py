@@ -34,8 +34,9 @@ def test_svtrv2_f32_matches_reference_golden(golden_dir, name):
     assert m.decode_probs(torch.from_numpy(g["log_probs"])) == want
 
 
-@pytest.mark.parametrize("dt,tol", [("bf16", 0.35), ("f16", 0.05)])
-def test_svtrv2_lowp_error_budget(golden_dir, dt, tol):
+# budgets = 1.5 x the values measured on MI355X in round 2 (bf16: 0.1444 / agreement 0.9938; f16: 0.0219 / 1.0000)
+@pytest.mark.parametrize("dt,tol,min_agree", [("bf16", 0.22, 0.99), ("f16", 0.033, 0.998)])
+def test_svtrv2_lowp_error_budget(golden_dir, dt, tol, min_agree):
     from ocr_vi_invoice_amd import SVTRv2, weights
     g = np.load(os.path.join(golden_dir, "rec_base_48x320.npz"))
     sd = weights.make_rec_state_dict("base", seed=int(g["seed"]))
@@ -44,7 +45,7 @@ def test_svtrv2_lowp_error_budget(golden_dir, dt, tol):
     err = np.abs(lp - g["log_probs"]).max()
     agree = (lp.argmax(-1).T == g["argmax_ids"]).mean()
     print(f"\n[{dt}] log_probs max-abs-err {err:.4f} (logit range ~25), per-step argmax agreement {agree:.4f}")
-    assert err < tol and agree > 0.97
+    assert err < tol and agree > min_agree
 
 
 def test_svtrv2_batch_invariance_and_ragged_batch():
@@ -114,7 +115,8 @@ def test_dbnet_f32_matches_oracle(hw):
     assert set(only) == {"binary"} and torch.equal(only["binary"], out["binary"])
 
 
-@pytest.mark.parametrize("dt,tol", [("bf16", 0.25), ("f16", 0.05)])
+# budgets = 1.5 x the values measured on MI355X in round 2 (binary-map max-abs-err: bf16 0.0218, f16 0.0035)
+@pytest.mark.parametrize("dt,tol", [("bf16", 0.033), ("f16", 0.0053)])
 def test_dbnet_lowp_error_budget(dt, tol):
     from ocr_vi_invoice_amd import DBNetPP, synth, weights
     from oracle import dbnet_cpu
