@@ -16,7 +16,10 @@
 //   * epilogue: + bias + fp32 residual -> x; optionally LayerNorm of the result with the NEXT block's norm1 (or a plain cast) -> xn,
 //     which removes that LayerNorm / cast kernel too.
 // Per token tile the CU streams 4*D/64 * 256*D bytes of weights from L2 (2.36 MB at D = 384) for 2*128*8*D*D FLOP: 131 FLOP/B.
+#include <stdlib.h>
 #include <string.h>
+
+#include <utility>
 
 #include "gemm_ring.h"
 #include "kernels.h"
@@ -44,6 +47,17 @@ template <typename T> __device__ __forceinline__ uint32_t pack2(float a, float b
     return r.u;
 }
 
+template <int I> struct ICm { static constexpr int value = I; };
+template <typename F, int... Is> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(ICm<Is>{}), ...); }
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// Software pipeline over the hidden chunks (one wave per SIMD cannot overlap its own GELU with its own MFMAs unless the instruction
+// stream interleaves them): while chunk c's bias + GELU runs on the VALU, the matrix pipe works on GEMM1 of chunk c + 1 and GEMM2 of
+// chunk c - 1.  Two GEMM1 accumulator sets and two packed-h sets alternate (chunk parity), so every register index is static.
+//   G1(0);  [G1(1) | gelu_a(0)];  gelu_b(0);
+//   for c = 1 .. NCH-2:  [G1(c+1) | gelu_a(c)];  [G2(c-1) | gelu_b(c)];
+//   gelu_a(NCH-1);  [G2(NCH-2) | gelu_b(NCH-1)];  G2(NCH-1)
+// The weight stream is packed in exactly that order (pack_mlp_stream).
 template <typename T, int D, int WPS, int R>
 __global__ __launch_bounds__(256, WPS) void mlp_fused_kernel(const MlpParams p) {
     constexpr int KS = D / 64;         // 128-byte K-steps of GEMM1
@@ -52,7 +66,8 @@ __global__ __launch_bounds__(256, WPS) void mlp_fused_kernel(const MlpParams p) 
     constexpr int PPT = NCH * 2 * NP;  // pieces per token tile
     constexpr int PF = R - 1;          // pieces in flight
     constexpr int NB2 = D / 16;        // 16-channel output blocks
-    static_assert(D % 128 == 0 && D <= 384, "D");
+    constexpr int GR = 4 * NP;         // groups of 8 MFMAs in one GEMM part
+    static_assert(D % 128 == 0 && D <= 384 && NCH % 2 == 0 && NCH >= 4, "D");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     float* const c_b1 = (float*)(smem + R * kPiece);   // [4D]
@@ -79,31 +94,31 @@ __global__ __launch_bounds__(256, WPS) void mlp_fused_kernel(const MlpParams p) 
     const int ntiles = (p.M + 127) >> 7;
     const int G = gridDim.x;
     const int my_tiles = (ntiles - (int)blockIdx.x + G - 1) / G;
-    const int total = my_tiles * PPT;  // pieces this workgroup consumes
 
     // ---- weight ring: piece q of the stream is piece (q % PPT) of the packed buffer; this wave issues DMA instructions wave, wave + 4,
-    // wave + 8, wave + 12 of its 16 (8 row-slots x 128 B each); the XOR swizzle is applied on the source chunk (rule 21)
+    // wave + 8, wave + 12 of its 16 (8 row-slots x 128 B each); the XOR swizzle is applied on the source chunk (rule 21).  The ring
+    // step is branch-free: past the end of the workgroup's stream it keeps fetching pieces nobody reads (their slots are free), which
+    // are drained before the kernel ends.
     const int prow = lane >> 3;
     const unsigned voff = (unsigned)((8 * wave + prow) * 128 + (((lane & 7) ^ swz128(8 * wave + prow)) << 4));
     const char* const wbase = uniform_ptr((const char*)p.wstream);
-    int prod = 0, prod_mod = 0;
+    int prod_slot = 0, prod_mod = 0, cons_slot = 0;
     auto issue_piece = [&]() {
         const char* src = wbase + (size_t)prod_mod * kPiece;
-        const unsigned dst = lds0 + (prod % R) * kPiece + wave * 1024;
+        const unsigned dst = lds0 + prod_slot * kPiece + wave * 1024;
 #pragma unroll
         for (int j = 0; j < 4; ++j) glds16(src + j * 4096, voff, __builtin_amdgcn_readfirstlane(dst + j * 4096));
-        ++prod;
-        if (++prod_mod == PPT) prod_mod = 0;
+        prod_slot = prod_slot + 1 == R ? 0 : prod_slot + 1;
+        prod_mod = prod_mod + 1 == PPT ? 0 : prod_mod + 1;
     };
-    int cons = 0;
-    auto next_piece = [&]() -> const char* {  // wait for piece `cons`, free the slot of piece cons - 1, keep the ring full
-        if (total - 1 - cons >= PF - 1) wait_vm_barrier<(PF - 1) * 4>(); else wait_vm_barrier<0>();
-        if (prod < total) issue_piece();
-        const char* s = smem + (cons % R) * kPiece;
-        ++cons;
+    auto next_piece = [&]() -> const char* {  // wait for the oldest piece in flight, free the slot before it, keep the ring full
+        wait_vm_barrier<(PF - 1) * 4>();
+        issue_piece();
+        const char* s = smem + cons_slot * kPiece;
+        cons_slot = cons_slot + 1 == R ? 0 : cons_slot + 1;
         return s;
     };
-    for (int i = 0; i < PF && i < total; ++i) issue_piece();
+    for (int i = 0; i < PF; ++i) issue_piece();
 
     const int swa = swz128(lr);
     const int fo0 = ((2 * g) ^ swa) << 4, fo1 = ((2 * g + 1) ^ swa) << 4;
@@ -114,56 +129,51 @@ __global__ __launch_bounds__(256, WPS) void mlp_fused_kernel(const MlpParams p) 
         // ---- prologue: LayerNorm(x) of this wave's 32 tokens -> B-operand fragments.  Lane (lr, g) of token block b owns channels
         // 64 ks + 16 g .. + 16 of token tok0 + 16 b + lr for every K-step ks: its two 8-element halves are the two MFMA k-slots.
         uint4 xf[KS][2][2];  // [ks][half][token block]
-        {
-            float xv[2][KS][16];
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const int tok = min(tok0 + 16 * b + lr, p.M - 1);
-                const float* xr = p.x + (size_t)tok * D + 16 * g;
+        for (int b = 0; b < 2; ++b) {
+            float xv[KS][16];
+            const int tok = min(tok0 + 16 * b + lr, p.M - 1);
+            const float* xr = p.x + (size_t)tok * D + 16 * g;
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
+            for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float4 v = *(const float4*)(xr + 64 * ks + 4 * q);
-                        xv[b][ks][4 * q] = v.x; xv[b][ks][4 * q + 1] = v.y; xv[b][ks][4 * q + 2] = v.z; xv[b][ks][4 * q + 3] = v.w;
-                    }
-            }
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                float sum = 0.f;
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) sum += xv[b][ks][e];
-                sum += __shfl_xor(sum, 16);
-                sum += __shfl_xor(sum, 32);
-                const float mean = sum / (float)D;
-                float sq = 0.f;
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) { const float d = xv[b][ks][e] - mean; sq += d * d; }
-                sq += __shfl_xor(sq, 16);
-                sq += __shfl_xor(sq, 32);
-                const float rstd = rsqrtf(sq / (float)D + 1e-5f);
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    float o[16];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float4 gv = *(const float4*)(c_g + 64 * ks + 16 * g + 4 * q), bv = *(const float4*)(c_be + 64 * ks + 16 * g + 4 * q);
-                        o[4 * q] = (xv[b][ks][4 * q] - mean) * rstd * gv.x + bv.x;
-                        o[4 * q + 1] = (xv[b][ks][4 * q + 1] - mean) * rstd * gv.y + bv.y;
-                        o[4 * q + 2] = (xv[b][ks][4 * q + 2] - mean) * rstd * gv.z + bv.z;
-                        o[4 * q + 3] = (xv[b][ks][4 * q + 3] - mean) * rstd * gv.w + bv.w;
-                    }
-                    xf[ks][0][b] = make_uint4(pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]), pack2<T>(o[4], o[5]), pack2<T>(o[6], o[7]));
-                    xf[ks][1][b] = make_uint4(pack2<T>(o[8], o[9]), pack2<T>(o[10], o[11]), pack2<T>(o[12], o[13]), pack2<T>(o[14], o[15]));
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = *(const float4*)(xr + 64 * ks + 4 * q);
+                    xv[ks][4 * q] = v.x; xv[ks][4 * q + 1] = v.y; xv[ks][4 * q + 2] = v.z; xv[ks][4 * q + 3] = v.w;
                 }
+            float sum = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sum += xv[ks][e];
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            const float mean = sum / (float)D;
+            float sq = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { const float d = xv[ks][e] - mean; sq += d * d; }
+            sq += __shfl_xor(sq, 16);
+            sq += __shfl_xor(sq, 32);
+            const float rstd = rsqrtf(sq / (float)D + 1e-5f);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                float o[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 gv = *(const float4*)(c_g + 64 * ks + 16 * g + 4 * q), bv = *(const float4*)(c_be + 64 * ks + 16 * g + 4 * q);
+                    o[4 * q] = (xv[ks][4 * q] - mean) * rstd * gv.x + bv.x;
+                    o[4 * q + 1] = (xv[ks][4 * q + 1] - mean) * rstd * gv.y + bv.y;
+                    o[4 * q + 2] = (xv[ks][4 * q + 2] - mean) * rstd * gv.z + bv.z;
+                    o[4 * q + 3] = (xv[ks][4 * q + 3] - mean) * rstd * gv.w + bv.w;
+                }
+                xf[ks][0][b] = make_uint4(pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]), pack2<T>(o[4], o[5]), pack2<T>(o[6], o[7]));
+                xf[ks][1][b] = make_uint4(pack2<T>(o[8], o[9]), pack2<T>(o[10], o[11]), pack2<T>(o[12], o[13]), pack2<T>(o[14], o[15]));
             }
         }
-        // every VMEM op issued so far (ring DMAs, the previous tile's stores, the loads above) has completed: the counted waits of
-        // the main loop start from an empty queue
+        // every VMEM op issued so far by this wave (ring DMAs, the previous tile's stores, the loads above) has completed: the counted
+        // waits of the main loop start from the DMAs issued from here on (any older piece has landed)
         wait_vm_only<0>();
 
         f32x4 acc2[NB2][2];
@@ -172,66 +182,100 @@ __global__ __launch_bounds__(256, WPS) void mlp_fused_kernel(const MlpParams p) 
             acc2[a][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
             acc2[a][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        for (int hc = 0; hc < NCH; ++hc) {
-            // ---- GEMM1: hidden chunk [64 hc, +64) of fc1 for this wave's 32 tokens
-            f32x4 acc1[4][2];
+        f32x4 accA[4][2], accB[4][2];
+        uint32_t hfA[2][2][4], hfB[2][2][4];   // [k-slot half][token block][word]
+
+        // bias + exact GELU of pair `PP` (0..15) of chunk c: half hh = PP >> 3 (the k-slot half of GEMM2 it lands in), token block
+        // b = (PP >> 2) & 1, word jp = PP & 3  <->  hidden 16 (2 hh + (jp >> 1)) + 4 g + 2 (jp & 1) + {0, 1}
+        auto gelu_pair = [&](auto PP, const f32x4 (&acc)[4][2], uint32_t (&hf)[2][2][4], int c) {
+            constexpr int pp = decltype(PP)::value, hh = pp >> 3, b = (pp >> 2) & 1, jp = pp & 3, a = 2 * hh + (jp >> 1), r0 = 2 * (jp & 1);
+            const float2 bv = *(const float2*)(c_b1 + 64 * c + 16 * a + 4 * g + r0);
+            hf[hh][b][jp] = pack2<T>(gelu_erf(acc[a][b][r0] + bv.x), gelu_erf(acc[a][b][r0 + 1] + bv.y));
+        };
+        // GELU pairs [8 HALF + 8 k / GR, 8 HALF + 8 (k + 1) / GR) ride behind MFMA group k of a part
+        auto gelu_slice = [&](auto HALF, auto K, const f32x4 (&acc)[4][2], uint32_t (&hf)[2][2][4], int c) {
+            constexpr int half = decltype(HALF)::value, k = decltype(K)::value;
+            if constexpr (half >= 0) {
+                constexpr int lo = 8 * k / GR, hi = 8 * (k + 1) / GR;
+                static_for<hi - lo>([&](auto J) { gelu_pair(ICm<8 * half + lo + decltype(J)::value>{}, acc, hf, c); });
+            }
+        };
+        // GEMM1 of one chunk into `dst` (its NP pieces come next in the stream); GELU half HALF (-1: none) of chunk c from `src` rides along
+        auto g1 = [&](f32x4 (&dst)[4][2], auto HALF, const f32x4 (&src)[4][2], uint32_t (&hf)[2][2][4], int c) {
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
-                acc1[a][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                acc1[a][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                dst[a][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                dst[a][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
-#pragma unroll
-            for (int p1 = 0; p1 < NP; ++p1) {
+            static_for<NP>([&](auto P1) {
+                constexpr int p1 = decltype(P1)::value;
                 const char* S = next_piece();
+                // fragments of group q = kk * 2 + h are read one group ahead of their MFMAs (two register sets)
+                uint4 wf[2][4];
+                auto rd = [&](auto Q) {
+                    constexpr int q = decltype(Q)::value;
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
+                    for (int a = 0; a < 4; ++a) wf[q & 1][a] = *(const uint4*)(S + ((q >> 1) * 64 + a * 16 + lr) * 128 + ((q & 1) ? fo1 : fo0));
+                };
+                rd(ICm<0>{});
+                static_for<4>([&](auto Q) {
+                    constexpr int q = decltype(Q)::value;
+                    if constexpr (q + 1 < 4) rd(ICm<q + 1>{});
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int fo = h == 0 ? fo0 : fo1;
-                        uint4 wf[4];
-#pragma unroll
-                        for (int a = 0; a < 4; ++a) wf[a] = *(const uint4*)(S + (kk * 64 + a * 16 + lr) * 128 + fo);
-#pragma unroll
-                        for (int a = 0; a < 4; ++a) {
-                            Mma<T>::half(wf[a], xf[2 * p1 + kk][h][0], acc1[a][0]);
-                            Mma<T>::half(wf[a], xf[2 * p1 + kk][h][1], acc1[a][1]);
-                        }
+                    for (int a = 0; a < 4; ++a) {
+                        Mma<T>::half(wf[q & 1][a], xf[2 * p1 + (q >> 1)][q & 1][0], dst[a][0]);
+                        Mma<T>::half(wf[q & 1][a], xf[2 * p1 + (q >> 1)][q & 1][1], dst[a][1]);
                     }
-            }
-            // ---- bias + exact GELU; the lane's 16 hidden units per token become its two k-slot halves of GEMM2:
-            // half h', element j  <->  hidden 16 (2 h' + (j >> 2)) + 4 g + (j & 3)   (fc2's columns are packed in that order)
-            uint4 hf[2][2];
+                    gelu_slice(HALF, ICm<4 * p1 + q>{}, src, hf, c);
+                });
+            });
+        };
+        // GEMM2 of one chunk (h = `hin`) into acc2; GELU half HALF of chunk c from `src` into `hf` rides along
+        auto g2 = [&](const uint32_t (&hin)[2][2][4], auto HALF, const f32x4 (&src)[4][2], uint32_t (&hf)[2][2][4], int c) {
+            uint4 hv[2][2];
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const float4 bA = *(const float4*)(c_b1 + 64 * hc + 16 * (2 * hh) + 4 * g), bB = *(const float4*)(c_b1 + 64 * hc + 16 * (2 * hh + 1) + 4 * g);
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const f32x4 u = acc1[2 * hh][b], v = acc1[2 * hh + 1][b];
-                    hf[hh][b] = make_uint4(pack2<T>(gelu_erf(u[0] + bA.x), gelu_erf(u[1] + bA.y)), pack2<T>(gelu_erf(u[2] + bA.z), gelu_erf(u[3] + bA.w)),
-                                           pack2<T>(gelu_erf(v[0] + bB.x), gelu_erf(v[1] + bB.y)), pack2<T>(gelu_erf(v[2] + bB.z), gelu_erf(v[3] + bB.w)));
-                }
-            }
-            // ---- GEMM2: all D outputs += fc2[:, chunk] . h
-#pragma unroll
-            for (int p2 = 0; p2 < NP; ++p2) {
+                for (int b = 0; b < 2; ++b) hv[h][b] = make_uint4(hin[h][b][0], hin[h][b][1], hin[h][b][2], hin[h][b][3]);
+            static_for<NP>([&](auto P2) {
+                constexpr int p2 = decltype(P2)::value;
                 const char* S = next_piece();
+                uint4 wf[2][4];  // group q = h * 2 + (output blocks 0-3 | 4-7), read one group ahead
+                auto rd = [&](auto Q) {
+                    constexpr int q = decltype(Q)::value;
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int fo = h == 0 ? fo0 : fo1;
+                    for (int a = 0; a < 4; ++a) wf[q & 1][a] = *(const uint4*)(S + (((q & 1) * 4 + a) * 16 + lr) * 128 + ((q >> 1) ? fo1 : fo0));
+                };
+                rd(ICm<0>{});
+                static_for<4>([&](auto Q) {
+                    constexpr int q = decltype(Q)::value;
+                    if constexpr (q + 1 < 4) rd(ICm<q + 1>{});
 #pragma unroll
-                    for (int a4 = 0; a4 < 8; a4 += 4) {
-                        uint4 wf[4];
-#pragma unroll
-                        for (int a = 0; a < 4; ++a) wf[a] = *(const uint4*)(S + ((a4 + a) * 16 + lr) * 128 + fo);
-#pragma unroll
-                        for (int a = 0; a < 4; ++a) {
-                            Mma<T>::half(wf[a], hf[h][0], acc2[p2 * 8 + a4 + a][0]);
-                            Mma<T>::half(wf[a], hf[h][1], acc2[p2 * 8 + a4 + a][1]);
-                        }
+                    for (int a = 0; a < 4; ++a) {
+                        Mma<T>::half(wf[q & 1][a], hv[q >> 1][0], acc2[p2 * 8 + (q & 1) * 4 + a][0]);
+                        Mma<T>::half(wf[q & 1][a], hv[q >> 1][1], acc2[p2 * 8 + (q & 1) * 4 + a][1]);
                     }
-                }
-            }
+                    gelu_slice(HALF, ICm<4 * p2 + q>{}, src, hf, c);
+                });
+            });
+        };
+        auto gelu_only = [&](auto HALF, const f32x4 (&src)[4][2], uint32_t (&hf)[2][2][4], int c) {
+            static_for<8>([&](auto J) { gelu_pair(ICm<8 * decltype(HALF)::value + decltype(J)::value>{}, src, hf, c); });
+        };
+        using NONE = ICm<-1>;
+        g1(accA, NONE{}, accA, hfA, 0);                 // G1(0)
+        g1(accB, ICm<0>{}, accA, hfA, 0);               // G1(1) | gelu_a(0)
+        gelu_only(ICm<1>{}, accA, hfA, 0);              // gelu_b(0)
+        for (int c = 1; c <= NCH - 3; c += 2) {
+            g1(accA, ICm<0>{}, accB, hfB, c);           // G1(c+1) | gelu_a(c)        (c odd: its GEMM1 sits in accB)
+            g2(hfA, ICm<1>{}, accB, hfB, c);            // G2(c-1) | gelu_b(c)
+            g1(accB, ICm<0>{}, accA, hfA, c + 1);       // G1(c+2) | gelu_a(c+1)
+            g2(hfB, ICm<1>{}, accA, hfA, c + 1);        // G2(c)   | gelu_b(c+1)
         }
+        gelu_only(ICm<0>{}, accB, hfB, NCH - 1);        // gelu_a(NCH-1)
+        g2(hfA, ICm<1>{}, accB, hfB, NCH - 1);          // G2(NCH-2) | gelu_b(NCH-1)
+        g2(hfB, NONE{}, accB, hfB, NCH - 1);            // G2(NCH-1)
+
         // ---- epilogue: x <- x + fc2(..) + b2 (lane: channels 16 a + 4 g .. + 4 of token tok0 + 16 b + lr), then the optional next norm
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
@@ -278,22 +322,25 @@ __global__ __launch_bounds__(256, WPS) void mlp_fused_kernel(const MlpParams p) 
             }
         }
     }
+    wait_vm_only<0>();  // the ring's run-ahead fetches
 }
 
 // ---------------------------------------------------------------- host: packing + launch
-// Stream order: for each hidden chunk hc: NP W1 pieces (piece p1 = K-steps 2 p1 and 2 p1 + 1, each 64 rows [hidden 64 hc + r] x 64
-// elements of K), then NP W2 pieces (piece p2 = output rows 128 p2 .. + 128, each 64 elements = hidden chunk hc in the k-slot order
+// Pieces: a chunk's fc1 slice is NP W1 pieces (piece p1 = K-steps 2 p1 and 2 p1 + 1, each 64 rows [hidden 64 hc + r] x 64
+// elements of K), its fc2 slice NP W2 pieces (piece p2 = output rows 128 p2 .. + 128, each 64 elements = hidden chunk hc in the k-slot order
 // the accumulator lanes produce: position 16 g + 8 h + j  <->  hidden 16 (2 h + (j >> 2)) + 4 g + (j & 3)).
 void pack_mlp_stream(const float* w1, const float* w2, int D, int dtype, std::vector<char>& out) {
     const int H4 = 4 * D, NCH = H4 / 64, NP = D / 128;
     const size_t esz = dtype_size(dtype);
     std::vector<float> buf((size_t)NCH * 2 * NP * (kPiece / esz));
     size_t o = 0;
-    for (int hc = 0; hc < NCH; ++hc) {
+    auto put_w1 = [&](int hc) {
         for (int p1 = 0; p1 < NP; ++p1)
             for (int kk = 0; kk < 2; ++kk)
                 for (int r = 0; r < 64; ++r)
                     for (int e = 0; e < 64; ++e) buf[o++] = w1[(size_t)(64 * hc + r) * D + 64 * (2 * p1 + kk) + e];
+    };
+    auto put_w2 = [&](int hc) {
         for (int p2 = 0; p2 < NP; ++p2)
             for (int n = 0; n < 128; ++n)
                 for (int pos = 0; pos < 64; ++pos) {
@@ -301,7 +348,16 @@ void pack_mlp_stream(const float* w1, const float* w2, int D, int dtype, std::ve
                     const int hid = 16 * (2 * h + (j >> 2)) + 4 * g + (j & 3);
                     buf[o++] = w2[(size_t)(128 * p2 + n) * H4 + 64 * hc + hid];
                 }
+    };
+    // consumption order of the software pipeline: G1(0), G1(1), then G1(c+1), G2(c-1) for c = 1 .. NCH-2, then G2(NCH-2), G2(NCH-1)
+    put_w1(0);
+    put_w1(1);
+    for (int c = 1; c <= NCH - 2; ++c) {
+        put_w1(c + 1);
+        put_w2(c - 1);
     }
+    put_w2(NCH - 2);
+    put_w2(NCH - 1);
     out.resize(buf.size() * esz);
     convert_to_dtype(buf.data(), buf.size(), dtype, out.data());
 }
@@ -325,7 +381,9 @@ static int launch_mlp(const MlpParams& p, hipStream_t s) {
 
 template <typename T> static int mlp_dt(const MlpParams& p, int D, hipStream_t s) {
     switch (D) {
-        case 128: return launch_mlp<T, 128, 2, 4>(p, s);   // 2 workgroups per CU (256 VGPRs each), 64-KiB ring
+        // (D = 128 would fit two workgroups per CU, but its 256-register build spills inside the pipeline and was measured wrong on MI355X;
+        //  one workgroup per CU with the full register file is the tested configuration for every D)
+        case 128: return launch_mlp<T, 128, 1, 9>(p, s);
         case 256: return launch_mlp<T, 256, 1, 9>(p, s);
         case 384: return launch_mlp<T, 384, 1, 9>(p, s);
     }
