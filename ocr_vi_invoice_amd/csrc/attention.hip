@@ -7,6 +7,8 @@
 //   softmax in registers (exp2 with the 1/sqrt(32) scale folded in), un-normalised P kept in the accumulators
 //   O^T = V^T P^T (MFMA A = V^T rows = head-dim, B = P straight from the accumulators; the K-order of the product is
 //                  permuted identically on both operands, cdna_hip_programming.md section 3)
+#include <stdlib.h>
+
 #include "kernels.h"
 
 namespace ocrvi {
@@ -40,7 +42,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
     constexpr int KROW = AttnCfg<T>::KROW;
     constexpr int CH = KROW / 16;  // 16-byte chunks per K row
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int h = blockIdx.x, b = blockIdx.y;
+    // heads of one sequence run back to back on one XCD: the 64-byte q/k/v slices of neighbouring heads share 128-byte lines in its L2
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int h = L % heads, b = L / heads;
     const int D = heads * 32, ld = 3 * D;
     constexpr int NP = ((MAXT + 1) / 2) * 32;  // key rows staged in LDS: whole 32-key PV steps (zero-filled past N)
     constexpr int VS = AttnCfg<T>::vstride(NP);
@@ -194,13 +198,193 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// 16-bit types: streaming two-pass kernel.  With head_dim = 32 one exp covers only 64 multiply-adds, so the kernel is bound by the
+// VALU (v_exp_f32 is quarter rate), not by MFMA issue: what matters is that the matrix pipe, the VALU and the LDS all stay busy at
+// once.  Holding a query tile's whole score row in registers (the kernel above: 120 VGPRs at 480 keys) caps the occupancy at two
+// waves per SIMD that run QK -> softmax -> PV as three serial phases.  Here a wave owns 32 queries (two 16-query MFMA tiles that
+// share every K / V fragment read) and streams the keys twice in blocks of 32:
+//   pass 1   S^T = K Q^T per 16-key tile -> running element-wise max (the scores are not kept)
+//   pass 2   S^T again -> p = exp2((s - max) * scale) -> 16-bit P straight from the accumulators into the PV MFMA; row sums by an
+//            MFMA against a ones fragment (sums of the ROUNDED P, as before)
+// ~90 VGPRs -> 8-wave workgroups, two per CU = 4 waves per SIMD; pass 1's extra QK MFMAs ride on the otherwise idle matrix pipe.
+// K is staged row-major [key][64 B] (XOR-swizzled, ds_read_b128 per fragment).  V is staged row-major too and read with the
+// hardware transpose (ds_read_b64_tr_b16): the A operand of O^T = V^T P^T needs, per lane, 4 consecutive keys of one head-dim column;
+// rows whose (key >> 2) is odd are stored with the two 8-byte halves of every 16-byte chunk swapped, which makes the 8 rows a
+// half-wave reads land on disjoint banks.  The 16 head-dim columns of MFMA block dt are 8 (i >> 2) + 4 dt + (i & 3), so a lane ends up
+// with 8 consecutive output channels (one 16-byte store, 64 contiguous bytes per query).  Workgroups are numbered so that the heads
+// of one sequence run back to back on one XCD: the 64-byte q/k/v slices of neighbouring heads share 128-byte lines through its L2.
+typedef short short4v __attribute__((ext_vector_type(4)));
+
+template <typename T, int NW, bool MASK>
+__global__ __launch_bounds__(NW * 64) void attention16_kernel(const T* __restrict__ qkv, T* __restrict__ out, int N, int heads) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int h = L % heads, b = L / heads;
+    const int D = heads * 32, ld = 3 * D;
+    const int NB = (N + 31) >> 5;           // 32-key blocks (rows past N are zero-filled)
+    char* const Ks = smem;
+    char* const Vs = smem + (size_t)NB * 32 * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const T* base = qkv + (size_t)b * N * ld + h * 32;
+
+    // ---- stage K and V rows (64 B each per key)
+    for (int idx = tid; idx < NB * 32 * 8; idx += NW * 64) {
+        const int key = idx >> 3, c = idx & 7;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (key < N) v = *(const uint4*)(base + (size_t)key * ld + (c < 4 ? D + c * 8 : 2 * D + (c - 4) * 8));
+        if (c < 4) {
+            *(uint4*)(Ks + key * 64 + ((c ^ swz64(key)) << 4)) = v;
+        } else {
+            if ((key >> 2) & 1) v = make_uint4(v.z, v.w, v.x, v.y);
+            *(uint4*)(Vs + key * 64 + ((c - 4) << 4)) = v;
+        }
+    }
+    __syncthreads();
+
+    const int lr = lane & 15, g = lane >> 4;
+    const float c2 = 0.17677669529663687f * 1.4426950408889634f;  // 32^-0.5 * log2(e)
+    const char* const kbase = Ks + lr * 64 + ((g ^ swz64(lr)) << 4);          // + 16-key tile * 1024
+    // transposed V read: lane 16 g + 4 q + p supplies row (key) 4 g + q of the block, head-dim columns 8 p + 4 dt .. + 4
+    const int tq = (lane >> 2) & 3, tp = lane & 3;
+    const unsigned vaddr0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)Vs + (4 * g + tq) * 64 + 16 * tp;
+    const unsigned vsel = (g & 1) * 8;      // half swap of rows with odd (key >> 2)
+    const T one = from_f32<T>(1.0f);
+    union { T e[8]; uint4 u; } ones;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) ones.e[r] = one;
+
+    const int NT = (N + 31) >> 5;           // 32-query tasks
+    for (int task = wave; task < NT; task += NW) {
+        uint4 qf[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const int q = task * 32 + 16 * qt + lr;
+            qf[qt] = make_uint4(0, 0, 0, 0);
+            if (q < N) qf[qt] = *(const uint4*)(base + (size_t)q * ld + 8 * g);
+        }
+        // ---- pass 1: row maxima
+        f32x4 m4[2] = {(f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY}, (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY}};
+        auto tile_max = [&](int t, bool mask) {
+            const uint4 kf = *(const uint4*)(kbase + t * 1024);
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                f32x4 sc = mfma16<T>(kf, qf[qt], (f32x4){0.f, 0.f, 0.f, 0.f});
+                if (mask) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sc[r] = (16 * t + 4 * g + r >= N) ? -INFINITY : sc[r];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) m4[qt][r] = fmaxf(m4[qt][r], sc[r]);
+            }
+        };
+        const int full16 = MASK ? (N >> 4) : 2 * NB;   // 16-key tiles without padding
+        for (int t = 0; t < full16; ++t) tile_max(t, false);
+        if constexpr (MASK) {
+            for (int t = full16; t < 2 * NB; ++t) tile_max(t, true);
+        }
+        float nm[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            float mx = fmaxf(fmaxf(m4[qt][0], m4[qt][1]), fmaxf(m4[qt][2], m4[qt][3]));
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            nm[qt] = -mx * c2;
+        }
+        // ---- pass 2: P and O^T = V^T P^T
+        f32x4 o[2][2], osum[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            o[qt][0] = o[qt][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            osum[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        auto block = [&](int s, bool mask) {
+            const uint4 kf0 = *(const uint4*)(kbase + s * 2048), kf1 = *(const uint4*)(kbase + s * 2048 + 1024);
+            uint4 vf[2];
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const unsigned a = vaddr0 + s * 2048 + ((8 * dt) ^ vsel);
+                const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(size_t)a);
+                const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(size_t)(a + 1024));
+                union { short4v v[2]; uint4 u; } pk;
+                pk.v[0] = lo; pk.v[1] = hi;
+                vf[dt] = pk.u;
+            }
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                f32x4 s0 = mfma16<T>(kf0, qf[qt], (f32x4){0.f, 0.f, 0.f, 0.f});
+                f32x4 s1 = mfma16<T>(kf1, qf[qt], (f32x4){0.f, 0.f, 0.f, 0.f});
+                if (mask) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        s0[r] = (32 * s + 4 * g + r >= N) ? -INFINITY : s0[r];
+                        s1[r] = (32 * s + 16 + 4 * g + r >= N) ? -INFINITY : s1[r];
+                    }
+                }
+                union { T e[8]; uint4 u; } pf;   // k-slot (g, j)  <->  key 32 s + 16 (j >> 2) + 4 g + (j & 3)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pf.e[r] = from_f32<T>(__builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c2, nm[qt])));
+                    pf.e[4 + r] = from_f32<T>(__builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c2, nm[qt])));
+                }
+                osum[qt] = mfma16<T>(ones.u, pf.u, osum[qt]);
+                o[qt][0] = mfma16<T>(vf[0], pf.u, o[qt][0]);
+                o[qt][1] = mfma16<T>(vf[1], pf.u, o[qt][1]);
+            }
+        };
+        const int full32 = MASK ? (N >> 5) : NB;
+        for (int s = 0; s < full32; ++s) block(s, false);
+        if constexpr (MASK) {
+            for (int s = full32; s < NB; ++s) block(s, true);
+        }
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const int q = task * 32 + 16 * qt + lr;
+            if (q < N) {
+                const float inv = 1.f / osum[qt][0];
+                union { T e[8]; uint4 u; } pk;   // head-dim 8 g + 4 dt + r
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pk.e[r] = from_f32<T>(o[qt][0][r] * inv);
+                    pk.e[4 + r] = from_f32<T>(o[qt][1][r] * inv);
+                }
+                *(uint4*)(out + ((size_t)b * N + q) * D + h * 32 + 8 * g) = pk.u;
+            }
+        }
+    }
+}
+
+template <typename T, int NW>
+static int launch_attn16(const void* qkv, void* out, int B, int N, int heads, hipStream_t s) {
+    const int NB = (N + 31) / 32;
+    const int smem = NB * 32 * 128;
+    if (N % 32 == 0) {
+        auto kern = attention16_kernel<T, NW, false>;
+        OCRVI_TRY(ensure_max_smem((const void*)kern, smem));
+        hipLaunchKernelGGL(kern, dim3(heads * B), dim3(NW * 64), smem, s, (const T*)qkv, (T*)out, N, heads);
+    } else {
+        auto kern = attention16_kernel<T, NW, true>;
+        OCRVI_TRY(ensure_max_smem((const void*)kern, smem));
+        hipLaunchKernelGGL(kern, dim3(heads * B), dim3(NW * 64), smem, s, (const T*)qkv, (T*)out, N, heads);
+    }
+    OCRVI_HIP(hipGetLastError());
+    return OCRVI_OK;
+}
+template <typename T>
+static int attn16_dt(const void* qkv, void* out, int B, int N, int heads, hipStream_t s) {
+    const int tasks = (N + 31) / 32;
+    if (tasks <= 2) return launch_attn16<T, 2>(qkv, out, B, N, heads, s);
+    if (tasks <= 4) return launch_attn16<T, 4>(qkv, out, B, N, heads, s);
+    return launch_attn16<T, 8>(qkv, out, B, N, heads, s);
+}
+
 template <typename T, int MAXT, bool MASK>
 static int launch_attn_m(const void* qkv, void* out, int B, int N, int heads, hipStream_t s) {
     constexpr int NP = ((MAXT + 1) / 2) * 32;
     const int smem = NP * AttnCfg<T>::KROW + 32 * AttnCfg<T>::vstride(NP);
     auto kern = attention_kernel<T, MAXT, MASK>;
     OCRVI_TRY(ensure_max_smem((const void*)kern, smem));
-    hipLaunchKernelGGL(kern, dim3(heads, B), dim3(256), smem, s, (const T*)qkv, (T*)out, N, heads);
+    hipLaunchKernelGGL(kern, dim3(heads * B), dim3(256), smem, s, (const T*)qkv, (T*)out, N, heads);
     OCRVI_HIP(hipGetLastError());
     return OCRVI_OK;
 }
@@ -230,10 +414,14 @@ int k_attention(int dtype, const void* qkv, void* out, int B, int N, int heads, 
     snprintf(tag, sizeof(tag), "attention_hd32_%s", dtype_name(dtype));
     const double esz = (double)dtype_size(dtype);
     ProfScope ps(tag, 4.0 * B * heads * (double)N * N * 32, (double)B * N * heads * 32 * 4 * esz, s);
+    // 16-bit types: the streaming two-pass kernel wins from ~256 keys up (measured on MI355X: 480 keys 127 us vs 145 us for 256 x 8 heads;
+    // 240 keys 75 vs 65 us), the register-resident kernel below that.  OCRVI_ATTN_STREAM=0 forces the latter (A/B switch).
+    static const bool streaming = !(getenv("OCRVI_ATTN_STREAM") && atoi(getenv("OCRVI_ATTN_STREAM")) == 0);
+    OCRVI_CHECK((size_t)B * heads < ((size_t)1 << 31), OCRVI_EINVAL, "attention: too many (sequence, head) pairs");
     switch (dtype) {
         case OCRVI_F32: return attn_dt<float>(qkv, out, B, N, heads, s);
-        case OCRVI_BF16: return attn_dt<bf16_t>(qkv, out, B, N, heads, s);
-        case OCRVI_F16: return attn_dt<f16_t>(qkv, out, B, N, heads, s);
+        case OCRVI_BF16: return streaming && N > 256 ? attn16_dt<bf16_t>(qkv, out, B, N, heads, s) : attn_dt<bf16_t>(qkv, out, B, N, heads, s);
+        case OCRVI_F16: return streaming && N > 256 ? attn16_dt<f16_t>(qkv, out, B, N, heads, s) : attn_dt<f16_t>(qkv, out, B, N, heads, s);
     }
     set_error("unknown dtype %d", dtype);
     return OCRVI_EINVAL;

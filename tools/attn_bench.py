@@ -1,15 +1,17 @@
-"""Micro-benchmark of the attention kernel through the C ABI hook: python tools/attn_bench.py [dtype]"""
+#!/usr/bin/env python3
+"""Times the attention kernel (ocrvi_test_attention) at the recogniser's shapes: B sequences x N tokens x heads (head_dim 32)."""
 import ctypes as C, os, sys
 import torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-from ocr_vi_invoice_amd import _lib
-dt = sys.argv[1] if len(sys.argv) > 1 else "bf16"
-DT = {"f32": 0, "bf16": 1, "f16": 2}[dt]
-lib = _lib.load()
-for B, N, heads in [(256, 480, 8), (256, 240, 12), (768, 80, 12), (256, 256, 8), (256, 300, 8)]:
-    qkv = torch.randn(B, N, 3 * heads * 32, device="cuda")
-    out = torch.empty(B, N, heads * 32, device="cuda")
-    ms = C.c_float(0)
-    _lib.check(lib.ocrvi_test_attention(0, DT, qkv.data_ptr(), B, N, heads, out.data_ptr(), 20, C.byref(ms)))
-    fl = 4.0 * B * heads * N * N * 32
-    print(f"B={B} N={N} heads={heads}: {ms.value*1e3:8.1f} us  {fl/ms.value/1e9:7.1f} TF/s ({fl/ms.value/1e9/25:.1f}% of bf16 MFMA peak)")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ocr_vi_invoice_amd import _lib as L
+lib = L.load()
+for dt, name in ((1, "bf16"), (2, "f16")):
+    for B, N, heads in ((256, 480, 8), (256, 240, 12), (768, 80, 12)):
+        g = torch.Generator().manual_seed(1)
+        qkv = torch.randn(B, N, 3 * heads * 32, generator=g).cuda()
+        out = torch.empty(B, N, heads * 32, device="cuda")
+        ms = C.c_float(0)
+        L.check(lib.ocrvi_test_attention(0, dt, qkv.data_ptr(), B, N, heads, out.data_ptr(), 20, C.byref(ms)))
+        fl = 4.0 * B * heads * N * N * 32
+        by = B * N * heads * 32 * 4 * 2
+        print(f"{name} B={B} N={N} heads={heads}: {ms.value*1e3:8.1f} us  {fl/ms.value/1e9:8.1f} TFLOP/s ({fl/ms.value/1e9/2500*100:.1f}% of 2.5 PF)  {by/ms.value/1e6:7.0f} GB/s algorithmic", flush=True)
