@@ -52,6 +52,7 @@ struct ConvParams {
     int identity_pix = 0;  // 1x1, stride 1, pad 0: input pixel index == m (no decomposition needed)
     int epi_lds = 0;       // stage the output tile through LDS and store whole rows (ST_NHWC only; set by launch_conv)
     int res_in_store = 0;  // fp32 out + fp32 residual, no activation: add the residual in the coalesced store phase
+    int patch_lw = 7;      // dcn_pipe: a tile is a (128 >> patch_lw) x (1 << patch_lw) patch of output pixels
 };
 
 __device__ __forceinline__ int fastdiv(int n, unsigned long long mg) { return (int)(((unsigned long long)(unsigned)n * mg) >> 40); }
@@ -490,6 +491,13 @@ static inline int conv_bn_for(int n_g) {
     return bn > cap ? cap : bn;
 }
 static inline int conv_bke(int dtype) { return dtype == OCRVI_F32 ? 32 : 64; }
+
+// 16-bit deformable layers with whole 64-channel blocks run on dcn_pipe.h, whose K order is (channel block, tap, channel) instead of
+// (tap, channel): packer and launcher must agree, so both ask this.
+static inline bool dcn_pipe_packing(int dtype, int cin_g) {
+    static const bool on = !(getenv("OCRVI_DCN_PIPE") && atoi(getenv("OCRVI_DCN_PIPE")) == 0);   // A/B switch
+    return on && dtype != OCRVI_F32 && cin_g % 64 == 0;
+}
 
 template <typename T> int launch_conv(const ConvParams& p, int amode, hipStream_t stream);
 int launch_conv_dt(int dtype, const ConvParams& p, int amode, hipStream_t stream);

@@ -31,6 +31,15 @@ __device__ __forceinline__ void glds16(const char* sbase, unsigned voff, unsigne
                  : "v"(voff), "s"(sbase), "s"(lds_dst)
                  : "memory");
 }
+// same, L1-bypassing (sc1: served by the XCD's L2): for operands every CU streams once per step, so they do not evict the lines a
+// gather wants to find in the 32-KiB vector L1
+__device__ __forceinline__ void glds16_sc1(const char* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+}
 // same with a full per-lane 64-bit address (3x3 mode: border lanes are redirected to the zero page)
 __device__ __forceinline__ void glds16v(const void* gsrc, unsigned lds_dst) {
     unsigned keep;
@@ -51,6 +60,10 @@ template <int N> __device__ __forceinline__ void wait_vm_barrier() {
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void gload16(u32x4& dst, const void* gsrc) {  // asynchronous: dst is valid only after wait_vm_only + bind16
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(gsrc) : "memory");
+}
+// same from (wave-uniform 64-bit base in SGPRs + per-lane 32-bit byte offset): one VALU op per address instead of a 64-bit add chain
+__device__ __forceinline__ void gload16s(u32x4& dst, const char* sbase, unsigned voff) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
 }
 template <int N> __device__ __forceinline__ void wait_vm_only() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void bind16(u32x4& r) { asm volatile("" : "+v"(r)); }  // every later use of r is ordered after this point

@@ -8,6 +8,7 @@
 
 #include "conv_gemm.h"
 #include "gemm_ring.h"
+#include "dcn_pipe.h"
 
 namespace ocrvi {
 
@@ -123,6 +124,8 @@ PackedConv pack_conv(const float* w, const float* bias, int cout, int cin_g, int
                     for (int s = 0; s < kw; ++s) {
                         const float v = src[(c * kh + r) * kw + s];
                         if (amode == AM_ROWS) dst[r * 32 + s * 4 + c] = v;          // [filter row][pixel s][ch c of 4]
+                        else if (amode == AM_DCN && dcn_pipe_packing(dtype, cin_g))
+                            dst[((c >> 6) * kh * kw + r * kw + s) * 64 + (c & 63)] = v;  // [channel block][tap][64 ch] (dcn_pipe.h)
                         else dst[(r * kw + s) * cin_g + c] = v;                      // [tap][cin]
                     }
         }
@@ -285,9 +288,15 @@ int launch_conv_dt(int dtype, const ConvParams& p, int amode, hipStream_t stream
         q.identity_pix = (amode == AM_CONV1 && p.SH == 1 && p.SW == 1 && p.PH == 0 && p.PW == 0 && p.H == p.OH && p.W == p.OW &&
                           p.store_mode == ST_NHWC && p.res_mode != RES_UP2) ? 1 : 0;
         const bool ring = gemm_ring_eligible(q, amode, dtype);
+        const bool pipe = amode == AM_DCN && dcn_pipe_eligible(q, dtype);
         static const bool detail = getenv("OCRVI_PROF_DETAIL") != nullptr;
         if (ring && !detail)
             snprintf(tag, sizeof(tag), "gemm_ring_%s", dtype_name(dtype));
+        else if (pipe && !detail)
+            snprintf(tag, sizeof(tag), "dcn3x3_pipe128x%d_%s", p.Np % 256 == 0 ? 256 : 128, dtype_name(dtype));
+        else if (pipe)
+            snprintf(tag, sizeof(tag), "dcn3x3_pipe128x%d_%s M%d N%d K%d g%d s%d", p.Np % 256 == 0 ? 256 : 128, dtype_name(dtype), p.M, p.N_g, (int)kvalid,
+                     p.groups, p.SH);
         else if (detail)
             snprintf(tag, sizeof(tag), "%s%s_%dx%d_%s M%d N%d K%d g%d s%d", ring ? "ring_" : "", amode_name(amode, p), amode == AM_DCN ? 64 : 128, (amode == AM_DCN && p.Np % 256 == 0) ? 256 : conv_bn_for(p.N_g), dtype_name(dtype), p.M,
                      p.N_g, (int)kvalid, p.groups, p.SH);
