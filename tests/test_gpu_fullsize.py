@@ -8,9 +8,10 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def test_det_fullsize_determinism_and_independence():
+@pytest.mark.parametrize("dt", ["bf16", "f16"])   # f16 is BASELINE.json configs[4]'s dtype and bench.py's throughput mode
+def test_det_fullsize_determinism_and_independence(dt):
     from ocr_vi_invoice_amd import DBNetPP, synth
-    m = DBNetPP(pretrained=False, dtype="bf16", seed=1234)
+    m = DBNetPP(pretrained=False, dtype=dt, seed=1234)
     imgs = np.stack([synth.normalize_chw(synth.make_invoice(s, 960, 1280, 30)[0]) for s in range(4)])
     x = torch.from_numpy(imgs).cuda().repeat(4, 1, 1, 1)              # 16 pages: 4 distinct, each repeated 4x
     a = m(x)
@@ -31,9 +32,10 @@ def test_det_fullsize_determinism_and_independence():
     np.testing.assert_allclose(a["binary"].cpu().numpy(), torch.sigmoid(a["bin_logits"]).cpu().numpy(), atol=2e-6)
 
 
-def test_rec_fullsize_determinism_independence_and_decode_paths():
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+def test_rec_fullsize_determinism_independence_and_decode_paths(dt):
     from ocr_vi_invoice_amd import SVTRv2, synth
-    m = SVTRv2("base", dtype="bf16", seed=1234)
+    m = SVTRv2("base", dtype=dt, seed=1234)
     x = torch.from_numpy(synth.pad_crop_batch(synth.make_crops(7, 256, 48, 320), 48, 320)).cuda()
     lp = m(x)
     assert lp.shape == (80, 256, 232) and float(lp.max()) <= 0
