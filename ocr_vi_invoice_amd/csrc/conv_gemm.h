@@ -492,11 +492,15 @@ static inline int conv_bn_for(int n_g) {
 }
 static inline int conv_bke(int dtype) { return dtype == OCRVI_F32 ? 32 : 64; }
 
-// 16-bit deformable layers with whole 64-channel blocks run on dcn_pipe.h, whose K order is (channel block, tap, channel) instead of
-// (tap, channel): packer and launcher must agree, so both ask this.
+// Deformable layers with whole 128-byte channel blocks (64 channels in 16 bits, 32 in fp32) run on dcn_pipe.h, whose K order is
+// (channel block, tap, channel) instead of (tap, channel): packer and launcher must agree, so both ask this.
+static inline int dcn_pipe_block(int dtype) { return dtype == OCRVI_F32 ? 32 : 64; }
 static inline bool dcn_pipe_packing(int dtype, int cin_g) {
     static const bool on = !(getenv("OCRVI_DCN_PIPE") && atoi(getenv("OCRVI_DCN_PIPE")) == 0);   // A/B switch
-    return on && dtype != OCRVI_F32 && cin_g % 64 == 0;
+    // fp32: measured equal to conv_gemm's AM_DCN mode (both sit at ~56 % of the fp32 MFMA peak: with fp32 MFMAs 16x slower the gather is
+    // hidden either way and what is left is tile-count quantisation: 600 tiles of 128 pixels on 256 CUs), so fp32 stays on conv_gemm
+    static const bool on32 = getenv("OCRVI_DCN_PIPE_F32") && atoi(getenv("OCRVI_DCN_PIPE_F32")) != 0;
+    return on && (dtype != OCRVI_F32 || on32) && cin_g % dcn_pipe_block(dtype) == 0;
 }
 
 template <typename T> int launch_conv(const ConvParams& p, int amode, hipStream_t stream);

@@ -187,11 +187,9 @@ int launch_conv(const ConvParams& p_in, int amode, hipStream_t stream) {
         case AM_CONV3: return launch_mode<T, AM_CONV3>(p, stream);
         case AM_DCN:
             OCRVI_CHECK(p.offs && p.Cin_g % BKE == 0 && p.groups == 1, OCRVI_EINVAL, "dcn: needs offsets and Cin %% %d == 0", BKE);
-            if constexpr (sizeof(T) == 2) {
-                if (dcn_pipe_eligible(p, TypeInfo<T>::dtype)) return launch_dcn_pipe<T>(p, stream);
-                OCRVI_CHECK(!dcn_pipe_packing(TypeInfo<T>::dtype, p.Cin_g), OCRVI_EINVAL,
-                            "dcn: weights are packed for the pipelined kernel but this call is not eligible for it (epilogue / alignment)");
-            }
+            if (dcn_pipe_eligible(p, TypeInfo<T>::dtype)) return launch_dcn_pipe<T>(p, stream);
+            OCRVI_CHECK(!dcn_pipe_packing(TypeInfo<T>::dtype, p.Cin_g), OCRVI_EINVAL,
+                        "dcn: weights are packed for the pipelined kernel but this call is not eligible for it (epilogue / alignment)");
             return launch_mode<T, AM_DCN>(p, stream);
         default: break;
     }

@@ -1,4 +1,4 @@
-// Pipelined modulated deformable 3x3 convolution for the 16-bit types (torchvision.ops.deform_conv2d as called in dcn.py:48-57).
+// Pipelined modulated deformable 3x3 convolution (torchvision.ops.deform_conv2d as called in dcn.py:48-57), all three compute types.
 //
 // conv_gemm's AM_DCN mode runs gather -> wait -> blend -> LDS -> barrier -> MFMA -> barrier strictly in series per K-step and stages
 // both operands through registers, so every K-step pays a full L2 round trip (measured 13-16 % of the MFMA peak).  Here the same
@@ -22,12 +22,14 @@ namespace ocrvi {
 
 template <typename T, int BN>
 __global__ __launch_bounds__(512, 2) void dcn_pipe_kernel(const ConvParams p) {
-    constexpr int EPC = 8, BM = 128;
+    constexpr int EPC = TypeInfo<T>::EPC, BM = 128;     // elements per 16-byte chunk: 8 (16-bit types) or 4 (fp32)
+    constexpr int CB = 8 * EPC;                         // channels per K-step (128 bytes): 64 or 32
     constexpr int WST = BN * 128, SLAB = BM * 128;
     constexpr int NI = BN / 32;            // 16-channel MFMA blocks per wave (BN / 2 channels)
     constexpr int GW = BN / 64;            // weight DMA instructions per wave per stage (BN / 8 pieces over 8 waves)
     constexpr int GG = 8;                  // gather loads per lane per step: 2 (row, chunk) items x 4 corners
-    static_assert(sizeof(T) == 2 && (BN == 128 || BN == 256), "16-bit types");
+    static_assert(BN == 128 || BN == 256, "column tile");
+    constexpr bool PERM = sizeof(T) == 2;               // 16-bit output: weight rows permuted so a lane ends with 8 consecutive channels
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const Wr = smem;                                  // [3][BN][128 B]
     char* const Sl = smem + 3 * WST;                        // [2][128][128 B]
@@ -40,12 +42,12 @@ __global__ __launch_bounds__(512, 2) void dcn_pipe_kernel(const ConvParams p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int lr = lane & 15, g = lane >> 4;
     const char* const xbase = uniform_ptr((const char*)p.x);
-    const int rowb = p.Cin * 2;                                        // bytes per input pixel
-    const int nk = 9 * (p.Cin_g / 64);
+    const int rowb = p.Cin * (int)sizeof(T);                           // bytes per input pixel
+    const int nk = 9 * (p.Cin_g / CB);
     const int lw = p.patch_lw, PW = 1 << lw, PH = BM >> lw;            // patch: PH rows x PW columns of output pixels
     const int pcols = (p.OW + PW - 1) >> lw, prows = (p.OH + PH - 1) / PH;
     const int ntiles = p.Np / BN, mtiles = p.n_img * prows * pcols, total = mtiles * ntiles;
-    const int ldw_b = p.Kp * 2;
+    const int ldw_b = p.Kp * (int)sizeof(T);
 
     // gather items of this thread: rows grow = tid >> 3 and grow + 64 of the tile, 16-byte chunk gj = tid & 7 of the 128-byte K-step
     const int grow = tid >> 3, gj = tid & 7;
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(512, 2) void dcn_pipe_kernel(const ConvParams p) {
     // MFMA fragment addressing (conv_gemm / gemm_ring conventions; B rows permuted so a lane ends with 8 consecutive channels)
     const int swa = swz128(lr);
     const int foa0 = ((2 * g) ^ swa) << 4, foa1 = ((2 * g + 1) ^ swa) << 4;
-    const int brow = 8 * (lr >> 2) + (lr & 3), swb = swz128(brow);
+    const int brow = PERM ? 8 * (lr >> 2) + (lr & 3) : lr, swb = swz128(brow);
     const int fob0 = ((2 * g) ^ swb) << 4, fob1 = ((2 * g + 1) ^ swb) << 4;
 
     for (int tile = xcd_remap(blockIdx.x, gridDim.x); tile < total; tile += gridDim.x) {
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(512, 2) void dcn_pipe_kernel(const ConvParams p) {
         };
         auto issue_gather = [&](int ks, GSet& S) {
             const int cb = ks / 9, tap = ks - 9 * cb;
-            const unsigned coff = (unsigned)(p.cin_off + cb * 64 + gj * EPC) * 2u;   // byte offset of this lane's chunk inside a pixel
+            const unsigned coff = (unsigned)(p.cin_off + cb * CB + gj * EPC) * (unsigned)sizeof(T);   // byte offset of this lane's chunk inside a pixel
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
                 const int gi = tap * BM + grow + 64 * it;
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(512, 2) void dcn_pipe_kernel(const ConvParams p) {
                 const uint4 x0 = *(const uint4*)(As + foa), x1 = *(const uint4*)(As + 16 * 128 + foa);
 #pragma unroll
                 for (int a = 0; a < NI; ++a) {
-                    const uint4 wf = *(const uint4*)(Bs + (32 * (a >> 1) + 4 * (a & 1)) * 128 + fob);
+                    const uint4 wf = *(const uint4*)(Bs + (PERM ? 32 * (a >> 1) + 4 * (a & 1) : 16 * a) * 128 + fob);
                     Mma<T>::half(wf, x0, acc[a][0]);
                     Mma<T>::half(wf, x1, acc[a][1]);
                 }
@@ -199,30 +201,49 @@ __global__ __launch_bounds__(512, 2) void dcn_pipe_kernel(const ConvParams p) {
             step(s, SB, SA);          // blends s + 1 (set B), refills set A with s + 2
             if (s + 1 < nk) step(s + 1, SA, SB);
         }
-        // ---- epilogue: bias + activation, 8 consecutive channels per lane (16-byte stores, 64 contiguous bytes per pixel)
+        // ---- epilogue: bias + activation; one 16-byte store per lane (16-bit: 8 consecutive channels thanks to the row permutation,
+        // fp32: the accumulator's 4), 64 contiguous bytes per pixel and instruction
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const int m = pixel_of(wm * 32 + 16 * b + lr);
+            if constexpr (PERM) {
 #pragma unroll
-            for (int hh = 0; hh < NI / 2; ++hh) {
-                const int ch = wn * (BN / 2) + 32 * hh + 8 * g;   // within the column tile
-                const int n = n0 + ch;
-                if (m >= 0 && n < p.N_g) {
-                    float v[8];
+                for (int hh = 0; hh < NI / 2; ++hh) {
+                    const int n = n0 + wn * (BN / 2) + 32 * hh + 8 * g;
+                    if (m >= 0 && n < p.N_g) {
+                        float v[8];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        v[r] = acc[2 * hh][b][r];
-                        v[4 + r] = acc[2 * hh + 1][b][r];
+                        for (int r = 0; r < 4; ++r) {
+                            v[r] = acc[2 * hh][b][r];
+                            v[4 + r] = acc[2 * hh + 1][b][r];
+                        }
+                        if (p.bias) {
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) v[r] += p.bias[n + r];
+                        }
+                        if (p.act == ACT_RELU) {
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
+                        }
+                        *(uint4*)((T*)p.out + (size_t)m * p.ldo + p.out_coff + n) = Chunk<T>::pack(v);
                     }
-                    if (p.bias) {
+                }
+            } else {
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) v[r] += p.bias[n + r];
-                    }
-                    if (p.act == ACT_RELU) {
+                for (int a = 0; a < NI; ++a) {
+                    const int n = n0 + wn * (BN / 2) + 16 * a + 4 * g;
+                    if (m >= 0 && n < p.N_g) {
+                        float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
+                        if (p.bias) {
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
+                            for (int r = 0; r < 4; ++r) v[r] += p.bias[n + r];
+                        }
+                        if (p.act == ACT_RELU) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                        }
+                        *(uint4*)((T*)p.out + (size_t)m * p.ldo + p.out_coff + n) = Chunk<T>::pack(v);
                     }
-                    *(uint4*)((T*)p.out + (size_t)m * p.ldo + p.out_coff + n) = Chunk<T>::pack(v);
                 }
             }
         }
@@ -230,9 +251,10 @@ __global__ __launch_bounds__(512, 2) void dcn_pipe_kernel(const ConvParams p) {
 }
 
 static inline bool dcn_pipe_eligible(const ConvParams& p, int dtype) {
+    const size_t esz = dtype_size(dtype);
     return dcn_pipe_packing(dtype, p.Cin_g) && p.groups == 1 && p.Kp == 9 * p.Cin_g && p.Np % 128 == 0 && p.N_g % 8 == 0 &&
-           p.store_mode == ST_NHWC && p.res_mode == RES_NONE && !p.out_f32 && (p.act == ACT_NONE || p.act == ACT_RELU) && p.ldo % 8 == 0 &&
-           p.out_coff % 8 == 0 && p.offs != nullptr && (size_t)p.n_img * p.H * p.W * p.Cin * 2 < ((size_t)1 << 32);
+           p.store_mode == ST_NHWC && p.res_mode == RES_NONE && (!p.out_f32 || dtype == OCRVI_F32) && (p.act == ACT_NONE || p.act == ACT_RELU) &&
+           p.ldo % 8 == 0 && p.out_coff % 8 == 0 && p.offs != nullptr && (size_t)p.n_img * p.H * p.W * p.Cin * esz < ((size_t)1 << 32);
 }
 
 template <typename T>

@@ -124,8 +124,10 @@ PackedConv pack_conv(const float* w, const float* bias, int cout, int cin_g, int
                     for (int s = 0; s < kw; ++s) {
                         const float v = src[(c * kh + r) * kw + s];
                         if (amode == AM_ROWS) dst[r * 32 + s * 4 + c] = v;          // [filter row][pixel s][ch c of 4]
-                        else if (amode == AM_DCN && dcn_pipe_packing(dtype, cin_g))
-                            dst[((c >> 6) * kh * kw + r * kw + s) * 64 + (c & 63)] = v;  // [channel block][tap][64 ch] (dcn_pipe.h)
+                        else if (amode == AM_DCN && dcn_pipe_packing(dtype, cin_g)) {
+                            const int cb = dcn_pipe_block(dtype);                                          // [channel block][tap][ch] (dcn_pipe.h)
+                            dst[((c / cb) * kh * kw + r * kw + s) * cb + (c % cb)] = v;
+                        }
                         else dst[(r * kw + s) * cin_g + c] = v;                      // [tap][cin]
                     }
         }
