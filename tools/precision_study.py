@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--lines", type=int, default=30)
     ap.add_argument("--dtypes", default="f16,bf16")
     ap.add_argument("--det-pages", type=int, default=2)
+    ap.add_argument("--cpu-det-pages", type=int, default=0, help="also compare the fp32 detector with the CPU oracle on N full-size pages")
     ap.add_argument("--cpu-crops", type=int, default=0, help="also run the CPU oracle (fp32) on the first N crops and compare the f32-mode strings")
     args = ap.parse_args()
     from ocr_vi_invoice_amd import DBNetPP, SVTRv2, synth, weights
@@ -89,6 +90,35 @@ def main():
         b = DBNetPP(pretrained=False, state_dict=dsd, dtype=dt, device=dev)(x)["binary"].cpu()
         out["det_" + dt] = {"max_abs_err": float((b - d32).abs().max()), "mean_abs_err": float((b - d32).abs().mean()),
                             "thr0.3_flips": int(((b > 0.3) != (d32 > 0.3)).sum())}
+    if args.cpu_det_pages:
+        # fp32 mode vs the CPU oracle at FULL size (the -m gpu model tests do this at 64x96 .. 160x96): probability maps and the crop
+        # rectangles post-processing derives from the blended maps (bench.py's chain)
+        from oracle import dbnet_cpu
+        from ocr_vi_invoice_amd.pipeline import DBPostProcessor, db_boxes_batch
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+        bench = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bench)
+        torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+        n = args.cpu_det_pages
+        gpu = DBNetPP(pretrained=False, state_dict=dsd, dtype="f32", device=dev)(x[:n])
+        worst, rect_equal = {}, True
+        pp = DBPostProcessor(0.3, 0.5, 1000, 1.6)
+        for i in range(n):
+            ref = dbnet_cpu.forward(dsd, x[i:i + 1].cpu())
+            for k in ("binary", "thresh", "thresh_binary"):
+                worst[k] = max(worst.get(k, 0.0), float((gpu[k][i:i + 1].cpu() - ref[k]).abs().max()))
+            add = np.zeros((960, 1280), np.float32)
+            for r in rects:
+                if r[0] == i:
+                    sx, sy, sw, sh = bench.shrink_box(*r[1:])
+                    add[sy:sy + sh, sx:sx + sw] = 0.75
+            ma = (add + np.float32(0.25) * gpu["binary"][i, 0].cpu().numpy()).astype(np.float32)
+            mb = (add + np.float32(0.25) * ref["binary"][0, 0].numpy()).astype(np.float32)
+            ra, _, _ = db_boxes_batch(ma[None], pp)
+            rb, _, _ = db_boxes_batch(mb[None], pp)
+            rect_equal = rect_equal and np.array_equal(ra, rb)
+        out["det_f32_gpu_vs_cpu_oracle_fullsize"] = {"pages": n, "max_abs_err": worst, "crop_rects_equal": bool(rect_equal)}
     print(json.dumps(out, indent=1))
 
 
