@@ -64,13 +64,14 @@ __global__ __launch_bounds__(256, WPS) void mlp_fused_kernel(const MlpParams p) 
     constexpr int NP = D / 128;        // pieces per chunk and GEMM (W1: 2 K-steps x 64 rows; W2: 128 rows x 1 K-step)
     constexpr int NCH = 4 * D / 64;    // hidden chunks of 64
     constexpr int PPT = NCH * 2 * NP;  // pieces per token tile
-    constexpr int PF = R - 1;          // pieces in flight
+    constexpr int UNIT = NP * kPiece;  // one chunk-GEMM's weights: the ring's sync unit (one wait + barrier per unit, not per piece)
+    constexpr int PF = R - 1;          // units in flight
     constexpr int NB2 = D / 16;        // 16-channel output blocks
     constexpr int GR = 4 * NP;         // groups of 8 MFMAs in one GEMM part
     static_assert(D % 128 == 0 && D <= 384 && NCH % 2 == 0 && NCH >= 4, "D");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    float* const c_b1 = (float*)(smem + R * kPiece);   // [4D]
+    float* const c_b1 = (float*)(smem + R * UNIT);     // [4D]
     float* const c_b2 = c_b1 + 4 * D;                  // [D]
     float* const c_g = c_b2 + D;                       // norm2 gamma, beta, next gamma, beta: [D] each
     float* const c_be = c_g + D;
@@ -102,23 +103,24 @@ __global__ __launch_bounds__(256, WPS) void mlp_fused_kernel(const MlpParams p) 
     const int prow = lane >> 3;
     const unsigned voff = (unsigned)((8 * wave + prow) * 128 + (((lane & 7) ^ swz128(8 * wave + prow)) << 4));
     const char* const wbase = uniform_ptr((const char*)p.wstream);
+    constexpr int UPT = PPT / NP;      // units per token tile
     int prod_slot = 0, prod_mod = 0, cons_slot = 0;
-    auto issue_piece = [&]() {
-        const char* src = wbase + (size_t)prod_mod * kPiece;
-        const unsigned dst = lds0 + prod_slot * kPiece + wave * 1024;
+    auto issue_unit = [&]() {
+        const char* src = wbase + (size_t)prod_mod * UNIT;
+        const unsigned dst = lds0 + prod_slot * UNIT + wave * 1024;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) glds16(src + j * 4096, voff, __builtin_amdgcn_readfirstlane(dst + j * 4096));
+        for (int j = 0; j < 4 * NP; ++j) glds16(src + j * 4096, voff, __builtin_amdgcn_readfirstlane(dst + j * 4096));
         prod_slot = prod_slot + 1 == R ? 0 : prod_slot + 1;
-        prod_mod = prod_mod + 1 == PPT ? 0 : prod_mod + 1;
+        prod_mod = prod_mod + 1 == UPT ? 0 : prod_mod + 1;
     };
-    auto next_piece = [&]() -> const char* {  // wait for the oldest piece in flight, free the slot before it, keep the ring full
-        wait_vm_barrier<(PF - 1) * 4>();
-        issue_piece();
-        const char* s = smem + cons_slot * kPiece;
+    auto next_unit = [&]() -> const char* {  // wait for the oldest unit in flight, free the slot before it, keep the ring full
+        wait_vm_barrier<(PF - 1) * 4 * NP>();
+        issue_unit();
+        const char* s = smem + cons_slot * UNIT;
         cons_slot = cons_slot + 1 == R ? 0 : cons_slot + 1;
         return s;
     };
-    for (int i = 0; i < PF; ++i) issue_piece();
+    for (int i = 0; i < PF; ++i) issue_unit();
 
     const int swa = swz128(lr);
     const int fo0 = ((2 * g) ^ swa) << 4, fo1 = ((2 * g + 1) ^ swa) << 4;
@@ -207,9 +209,10 @@ __global__ __launch_bounds__(256, WPS) void mlp_fused_kernel(const MlpParams p) 
                 dst[a][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 dst[a][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
+            const char* const U1 = next_unit();
             static_for<NP>([&](auto P1) {
                 constexpr int p1 = decltype(P1)::value;
-                const char* S = next_piece();
+                const char* S = U1 + p1 * kPiece;
                 // fragments of group q = kk * 2 + h are read one group ahead of their MFMAs (two register sets)
                 uint4 wf[2][4];
                 auto rd = [&](auto Q) {
@@ -237,9 +240,10 @@ __global__ __launch_bounds__(256, WPS) void mlp_fused_kernel(const MlpParams p) 
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int b = 0; b < 2; ++b) hv[h][b] = make_uint4(hin[h][b][0], hin[h][b][1], hin[h][b][2], hin[h][b][3]);
+            const char* const U2 = next_unit();
             static_for<NP>([&](auto P2) {
                 constexpr int p2 = decltype(P2)::value;
-                const char* S = next_piece();
+                const char* S = U2 + p2 * kPiece;
                 uint4 wf[2][4];  // group q = h * 2 + (output blocks 0-3 | 4-7), read one group ahead
                 auto rd = [&](auto Q) {
                     constexpr int q = decltype(Q)::value;
@@ -366,7 +370,7 @@ bool mlp_fused_eligible(int dtype, int D) { return dtype != OCRVI_F32 && D % 128
 
 template <typename T, int D, int WPS, int R>
 static int launch_mlp(const MlpParams& p, hipStream_t s) {
-    const int smem = R * kPiece + (4 * D + 5 * D) * 4;
+    const int smem = R * (D / 128) * kPiece + (4 * D + 5 * D) * 4;
     auto kern = mlp_fused_kernel<T, D, WPS, R>;
     OCRVI_TRY(ensure_max_smem((const void*)kern, smem));
     int n_cu = 0;
@@ -383,9 +387,9 @@ template <typename T> static int mlp_dt(const MlpParams& p, int D, hipStream_t s
     switch (D) {
         // (D = 128 would fit two workgroups per CU, but its 256-register build spills inside the pipeline and was measured wrong on MI355X;
         //  one workgroup per CU with the full register file is the tested configuration for every D)
-        case 128: return launch_mlp<T, 128, 1, 9>(p, s);
-        case 256: return launch_mlp<T, 256, 1, 9>(p, s);
-        case 384: return launch_mlp<T, 384, 1, 9>(p, s);
+        case 128: return launch_mlp<T, 128, 1, 9>(p, s);    // ring: 9 units of 16 KiB
+        case 256: return launch_mlp<T, 256, 1, 4>(p, s);    //       4 units of 32 KiB
+        case 384: return launch_mlp<T, 384, 1, 3>(p, s);    //       3 units of 48 KiB
     }
     set_error("mlp_fused: D=%d unsupported", D);
     return OCRVI_EINVAL;
