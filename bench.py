@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--no-parity-check", action="store_true", help="skip the fp32-mode re-run of the last step's crops (CER of the benchmarked dtype)")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernel launches with HIP events")
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying captured HIP graphs")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="one stream, one step at a time: every kernel runs alone on the chip (the variant the rocprofv3 --stats summary under "
+                         "profiles/ is taken from, so that its per-kernel averages can be compared with the HIP-event figures)")
     return ap.parse_args()
 
 
@@ -199,7 +202,8 @@ class E2E:
 
     def capture(self):
         torch, a = self.torch, self.args
-        self.s_det, self.s_rec = torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev)
+        self.s_det = torch.cuda.Stream(self.dev)
+        self.s_rec = self.s_det if getattr(a, "no_overlap", False) else torch.cuda.Stream(self.dev)
         self.g_det, self.g_rec = None, None
         if self.det is not None:
             with torch.cuda.stream(self.s_det):
@@ -445,9 +449,12 @@ def run_mode(args, dtype, dev, cdev, det_blob, rec_blob, images_u8, boxes, local
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    done = []
     for _ in range(a.steps):
         pipe.step()
-    done = pipe.finish()                 # the last step's post-processing, recogniser batches and strings: inside the timed region
+        if a.no_overlap:
+            done.extend(pipe.finish())
+    done.extend(pipe.finish())           # the last step's post-processing, recogniser batches and strings: inside the timed region
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -583,7 +590,8 @@ def main():
                        "global_batch": world * args.batch, "det_chunk": args.det_chunk, "rec_batch": args.rec_batch,
                        "crops_per_step_rank0": n_crops, "boxes_per_page_min_max": [min(counts), max(counts)] if counts else None,
                        "weights": "seeded synthetic (no checkpoint ships)",
-                       "launch": ("eager" if args.no_graph else "hipGraph replay") + ", det stream || host post-processing || rec stream",
+                       "launch": ("eager" if args.no_graph else "hipGraph replay") +
+                                 (", one stream, one step at a time (--no-overlap)" if args.no_overlap else ", det stream || host post-processing || rec stream"),
                        "post_process": {"in_timed_region": bool(m1["detected"]), "host_threads": m1["post_threads"]},
                        "parallelism": f"replicas x{world}, images sharded, no collective"},
         }
