@@ -174,30 +174,49 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams 
             for (int i = 0; i < NA; ++i) a_off[i] = (unsigned)(min((i * NW + wave) * 8 + prow, last) * lda_b + chunk * 16);
         }
     };
-    auto issue_stage = [&](int slot) {  // DMA the stage at the issue cursor into ring slot `slot`, advance the cursor
-        const unsigned base = lds0 + slot * STAGE;
-        const char* const bk = b_tile + (size_t)i_ks * 128;
+    // DMA the stage at the issue cursor into a ring slot, piece by piece: begin_issue fixes the stage's constants, issue_piece(P) sends
+    // piece P of the G = NA + NB (A pieces first), end_issue advances the cursor.  The pieces of stage s + 2 are issued BETWEEN the MFMAs
+    // of step s (one per weight-fragment row), not in front of them: the two waves of a SIMD run in lockstep behind the step's barrier, so
+    // a block of G DMA statements (M0 save / set / restore around each) ahead of the MFMAs leaves the matrix pipe idle for its whole
+    // issue time on both waves at once; spread over the MFMA gaps the scalar and VMEM issue slots are free.  (Measured neutral to +2 %:
+    // the MFMA-bound shapes are clock-limited)
+    unsigned st_base = 0;
+    const char *st_bk = nullptr, *st_ak = nullptr, *st_zero = nullptr;
+    long long st_delta = 0;
+    int st_tap = 0;
+    auto begin_issue = [&](int slot) {
+        st_base = lds0 + slot * STAGE;
+        st_bk = b_tile + (size_t)i_ks * 128;
         if constexpr (C3) {
             const int r = i_tap / 3, c = i_tap - r * 3;
-            const long long delta = (long long)((r - 1) * p.W + (c - 1)) * lda_b + i_cb * 128;
-            const char* const zero = (const char*)p.zero_page + (lane & 7) * 16;
-#pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                const char* src = ((a_mask[i] >> i_tap) & 1u) ? a_ptr[i] + delta : zero;
-                glds16v(src, __builtin_amdgcn_readfirstlane(base + (i * NW + wave) * 1024));
+            st_delta = (long long)((r - 1) * p.W + (c - 1)) * lda_b + i_cb * 128;
+            st_zero = (const char*)p.zero_page + (lane & 7) * 16;
+            st_tap = i_tap;
+        } else {
+            st_ak = a_tile + (size_t)i_ks * 128;
+        }
+    };
+    auto issue_piece = [&](auto P) {
+        constexpr int pi = decltype(P)::value;
+        if constexpr (pi < NA) {
+            if constexpr (C3) {
+                const char* src = ((a_mask[pi] >> st_tap) & 1u) ? a_ptr[pi] + st_delta : st_zero;
+                glds16v(src, __builtin_amdgcn_readfirstlane(st_base + (pi * NW + wave) * 1024));
+            } else {
+                glds16(st_ak, a_off[pi], __builtin_amdgcn_readfirstlane(st_base + (pi * NW + wave) * 1024));
             }
+        } else if constexpr (pi < G) {
+            constexpr int i = pi - NA;
+            glds16(st_bk + (size_t)(i * NW * 8) * ldw_b, b_off, __builtin_amdgcn_readfirstlane(st_base + BM * 128 + (i * NW + wave) * 1024));
+        }
+    };
+    auto end_issue = [&]() {
+        if constexpr (C3) {
             if (++i_cb == cpb) {
                 i_cb = 0;
                 ++i_tap;
             }
-        } else {
-            const char* const ak = a_tile + (size_t)i_ks * 128;
-#pragma unroll
-            for (int i = 0; i < NA; ++i) glds16(ak, a_off[i], __builtin_amdgcn_readfirstlane(base + (i * NW + wave) * 1024));
         }
-#pragma unroll
-        for (int i = 0; i < NB; ++i)
-            glds16(bk + (size_t)(i * NW * 8) * ldw_b, b_off, __builtin_amdgcn_readfirstlane(base + BM * 128 + (i * NW + wave) * 1024));
         if (++i_ks == nk) {
             i_ks = 0;
             i_tap = 0;
@@ -206,6 +225,14 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams 
             if (i_mt < mtiles) setup_issue(i_mt);
         }
     };
+    auto issue_stage = [&](int slot) {  // the whole stage at once (pipeline fill)
+        begin_issue(slot);
+        issue_piece(IC<0>{}); issue_piece(IC<1>{}); issue_piece(IC<2>{}); issue_piece(IC<3>{});
+        issue_piece(IC<4>{}); issue_piece(IC<5>{}); issue_piece(IC<6>{}); issue_piece(IC<7>{});
+        end_issue();
+    };
+    static_assert(G <= 8 && G <= 2 * NI, "one DMA piece per weight-fragment row of a step");
+    constexpr bool SPREAD = !(F32O && MI >= 4);
 
     auto activate = [&](float (&v)[4]) {
         if (p.act == ACT_RELU) {
@@ -363,26 +390,43 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams 
             if (run && has_res) load_group(GRP, pmt);
         }
         const bool dma = s + 2 < nsteps;
-        if (dma) issue_stage((s + 2) % NSTAGE);
+        if (dma) begin_issue((s + 2) % NSTAGE);
         tick(1);
         const char* As = smem + (s % NSTAGE) * STAGE;
         const char* Bs = As + BM * 128;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        auto half = [&](auto H) {
+            constexpr int h = decltype(H)::value;
             const int foa = h == 0 ? foa0 : foa1, fob = h == 0 ? fob0 : fob1;
             uint4 xf[MI], wf[NI];
 #pragma unroll
             for (int b = 0; b < MI; ++b) xf[b] = *(const uint4*)(As + (wm * TM + b * 16 + lr) * 128 + foa);
 #pragma unroll
             for (int a = 0; a < NI; ++a) wf[a] = *(const uint4*)(Bs + (wn * TN + a_row(a) + brow) * 128 + fob);
-#pragma unroll
-            for (int a = 0; a < NI; ++a)
+            auto row = [&](auto A) {
+                constexpr int a = decltype(A)::value;
 #pragma unroll
                 for (int b = 0; b < MI; ++b) Mma<T>::half(wf[a], xf[b], acc[a][b]);
+                if constexpr (SPREAD && h * NI + a < G) {   // piece h NI + a of stage s + 2 rides in the shadow of this row's MFMAs
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (dma) issue_piece(IC<h * NI + a>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            row(IC<0>{}); row(IC<1>{}); row(IC<2>{}); row(IC<3>{});
+            static_assert(NI == 4, "four weight-fragment rows per wave");
             // with an fp32 residual slice in flight the second half's fragments must not be hoisted over the first half's MFMAs:
             // the kernel sits at the 256-VGPR limit (the other wave of the SIMD covers the exposed LDS latency)
             if constexpr (F32O && MI >= 4) __builtin_amdgcn_sched_barrier(0);
+        };
+        if constexpr (!SPREAD) {   // (the fp32-output 256-row build sits at the 256-VGPR limit: the scheduling fences would make it spill)
+            if (dma) {
+                issue_piece(IC<0>{}); issue_piece(IC<1>{}); issue_piece(IC<2>{}); issue_piece(IC<3>{});
+                issue_piece(IC<4>{}); issue_piece(IC<5>{}); issue_piece(IC<6>{}); issue_piece(IC<7>{});
+            }
         }
+        half(IC<0>{});
+        half(IC<1>{});
+        if (dma) end_issue();
         tick(2);
         if constexpr (grp >= 0) {
             if (run) {
