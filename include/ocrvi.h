@@ -130,6 +130,12 @@ int ocrvi_crop_resize_normalize(int device, const uint8_t* images, int n_img, in
 int ocrvi_db_postprocess(const float* prob, int H, int W, float thresh, float box_thresh, int max_candidates, float unclip_ratio,
                          float min_area, int32_t* points, int cap_points, int32_t* box_offsets, float* scores, int cap_boxes, int* n_boxes);
 
+/* Replaces unclip()'s Clipper call for a given offset distance (src/det/test.py:37-43: PyclipperOffset().AddPath(box, JT_ROUND,
+ * ET_CLOSEDPOLYGON); Execute(distance)[0]): pts int32 (x, y) pairs of a closed polygon -> the offset polygon after Clipper's closing
+ * union (raw round-join offset path, then the outline of its positive-winding region), int32 pairs in out[2*cap_pts]; *n_out points
+ * (0 when the input degenerates).  Host code; ocrvi_db_postprocess calls the same routine with distance = area * unclip_ratio / length. */
+int ocrvi_unclip_polygon(const int32_t* pts, int n_pts, double distance, int32_t* out, int cap_pts, int* n_out);
+
 /* Replaces the host middle of the per-image loop for a batch of pages (src/pipeline/pipeline2.py:320-343): post_processor(prob_map)
  * (src/det/test.py:55-106) on each of the n_pages host maps prob[n_pages][H][W] -> boxes divided by (scale_w, scale_h) with the int64
  * truncation of pipeline2.py:324-328 -> crop_image's clamped bounding rectangle in the orig_h x orig_w page (src/det/test.py:123-130).

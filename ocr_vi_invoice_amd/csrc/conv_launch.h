@@ -118,7 +118,14 @@ static int launch_mode(const ConvParams& p, hipStream_t stream) {
         OCRVI_CHECK(bn == 128, OCRVI_EINVAL, "dcn: needs N_g > 64 (got %d)", p.N_g);
         // 64-row tiles (half the in-flight corner loads); 256-wide N tiles when C_out allows so the gathered + blended A rows are
         // shared by twice as many output channels (the blend is the VALU bottleneck of this kernel)
-        if (p.Np % 256 == 0) return launch_tile<T, AMODE, 64, 256, 2, 2>(p, stream);
+        // ... unless 64-row tiles leave the second round of the chip's 2 x CUs workgroup slots mostly empty (layer4: 600 tiles on 512
+        // slots); 32-row tiles keep the sharing and halve the quantum (measured 1304 -> 1014 us there, 2-8 % slower elsewhere)
+        if (p.Np % 256 == 0) {
+            int n_cu = 0;
+            OCRVI_TRY(device_cus(&n_cu));
+            if (cdiv(p.M, 64) * (p.Np / 256) < 3 * n_cu) return launch_tile<T, AMODE, 32, 256, 1, 4>(p, stream);
+            return launch_tile<T, AMODE, 64, 256, 2, 2>(p, stream);
+        }
         return launch_tile<T, AMODE, 64, 128, 2, 2>(p, stream);
     } else if constexpr (AMODE == AM_ROWS) {
         OCRVI_CHECK(bn <= 64, OCRVI_EINVAL, "rows-mode stem conv: N_g=%d > 64 unsupported", p.N_g);

@@ -12,6 +12,7 @@
 #include <thread>
 #include <vector>
 
+#include "clip_union.h"
 #include "common.h"
 
 namespace {
@@ -270,8 +271,8 @@ double box_score(const float* prob, int H, int W, const std::vector<Pt>& box) {
 
 inline long long cround(double v) { return v < 0 ? (long long)(v - 0.5) : (long long)(v + 0.5); }  // ClipperLib::Round
 
-// pyclipper.PyclipperOffset().AddPath(box, JT_ROUND, ET_CLOSEDPOLYGON); Execute(delta)  (Clipper 6.4.2 DoOffset/OffsetPoint/DoRound,
-// arc tolerance 0.25), without the final self-union (only the bounding rectangle of the result is consumed downstream).
+// pyclipper.PyclipperOffset().AddPath(box, JT_ROUND, ET_CLOSEDPOLYGON); Execute(delta), first half: the raw offset path (Clipper 6.4.2
+// DoOffset / OffsetPoint / DoRound, arc tolerance 0.25).  Execute's closing self-union is unclip_polygon() below.
 void clipper_offset_round(const std::vector<Pt>& in, double delta, std::vector<Pt>& out) {
     out.clear();
     if (in.empty()) return;
@@ -333,7 +334,30 @@ void clipper_offset_round(const std::vector<Pt>& in, double delta, std::vector<P
     }
 }
 
+// unclip (src/det/test.py:37-43) for a given distance: raw offset path -> Clipper's closing union (clip_union.h) -> its outer polygon
+void unclip_polygon(const std::vector<Pt>& in, double delta, std::vector<Pt>& out) {
+    std::vector<Pt> raw;
+    clipper_offset_round(in, delta, raw);
+    std::vector<clipu::P2> path(raw.size()), outline;
+    for (size_t i = 0; i < raw.size(); ++i) path[i] = {raw[i].x, raw[i].y};
+    clipu::union_outline(path, outline);
+    out.resize(outline.size());
+    for (size_t i = 0; i < outline.size(); ++i) out[i] = {outline[i].x, outline[i].y};
+}
+
 }  // namespace
+
+extern "C" int ocrvi_unclip_polygon(const int32_t* pts, int n_pts, double distance, int32_t* out, int cap_pts, int* n_out) {
+    using namespace ocrvi;
+    OCRVI_CHECK(pts && out && n_out && n_pts >= 0 && cap_pts >= 0 && distance > 0, OCRVI_EINVAL, "unclip_polygon: bad argument");
+    std::vector<Pt> in(n_pts), res;
+    for (int i = 0; i < n_pts; ++i) in[i] = {pts[2 * i], pts[2 * i + 1]};
+    unclip_polygon(in, distance, res);
+    OCRVI_CHECK((int)res.size() <= cap_pts, OCRVI_ENOMEM, "unclip_polygon: %d points exceed the capacity %d", (int)res.size(), cap_pts);
+    for (size_t i = 0; i < res.size(); ++i) { out[2 * i] = res[i].x; out[2 * i + 1] = res[i].y; }
+    *n_out = (int)res.size();
+    return OCRVI_OK;
+}
 
 extern "C" int ocrvi_db_postprocess(const float* prob, int H, int W, float thresh, float box_thresh, int max_candidates, float unclip_ratio,
                                     float min_area, int32_t* points, int cap_points, int32_t* box_offsets, float* scores, int cap_boxes,
@@ -365,7 +389,7 @@ extern "C" int ocrvi_db_postprocess(const float* prob, int H, int W, float thres
         if (length == 0) continue;
         const double distance = area * (double)unclip_ratio / length;
         if (distance <= 0) continue;
-        clipper_offset_round(approx, distance, box);
+        unclip_polygon(approx, distance, box);
         if (box.size() < 4) continue;
         OCRVI_CHECK(nb < cap_boxes && np + (int)box.size() <= cap_points, OCRVI_ENOMEM, "db_postprocess: output capacity exceeded (%d boxes, %d points)",
                     cap_boxes, cap_points);

@@ -178,8 +178,8 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams 
     // piece P of the G = NA + NB (A pieces first), end_issue advances the cursor.  The pieces of stage s + 2 are issued BETWEEN the MFMAs
     // of step s (one per weight-fragment row), not in front of them: the two waves of a SIMD run in lockstep behind the step's barrier, so
     // a block of G DMA statements (M0 save / set / restore around each) ahead of the MFMAs leaves the matrix pipe idle for its whole
-    // issue time on both waves at once; spread over the MFMA gaps the scalar and VMEM issue slots are free.  (Measured neutral to +2 %:
-    // the MFMA-bound shapes are clock-limited)
+    // issue time on both waves at once; spread over the MFMA gaps the scalar and VMEM issue slots are free.  (Measured neutral to +2 %;
+    // the shader clock stays at 2.40 GHz in the fp32 ring, so the rest of its off-pipe time is not throttling: DESIGN.md section 5.)
     unsigned st_base = 0;
     const char *st_bk = nullptr, *st_ak = nullptr, *st_zero = nullptr;
     long long st_delta = 0;

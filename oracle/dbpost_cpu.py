@@ -12,10 +12,11 @@ container and ship no fixtures, so each is restated here from its published algo
   curves: 3 farthest-point passes to pick the two anchors, slice stack, final clean-up pass), ``cv2.contourArea`` (shoelace).
 * ``cv2.fillPoly`` + ``cv2.mean(roi, mask)``: polygon boundary lines (8-connected Bresenham) plus interior pixels.
 * ``shapely.Polygon.area / .length`` (shoelace / perimeter in double) and ``pyclipper.PyclipperOffset`` with JT_ROUND,
-  ET_CLOSEDPOLYGON, default arc tolerance 0.25 (ClipperOffset::DoOffset / OffsetPoint / DoRound of Clipper 6.4.2), without the final
-  self-union (it only removes the inner loops of concave joins: the bounding rectangle, which is all the pipeline uses, is unchanged).
+  ET_CLOSEDPOLYGON, default arc tolerance 0.25 (ClipperOffset::DoOffset / OffsetPoint / DoRound of Clipper 6.4.2) followed by
+  Execute's closing self-union (ctUnion, pftPositive), restated as the outline of the positive-winding region of the raw path with
+  Clipper's rounding of crossing points -- see clipper_union_outline for what is and is not claimed about the vertex order.
 
-The product implementation (csrc/dbpost.cpp, C++) is an independent statement of the same algorithms and must agree exactly.
+The product implementation (csrc/dbpost.hip + csrc/clip_union.h, host C++) is an independent statement of the same algorithms and must agree exactly.
 """
 from __future__ import annotations
 
@@ -263,7 +264,7 @@ def _round_half_away(v: float) -> int:
 
 
 def clipper_offset_round(pts: np.ndarray, delta: float) -> np.ndarray:
-    """ClipperOffset (6.4.2) AddPath(JT_ROUND, ET_CLOSEDPOLYGON) + Execute(delta), arc tolerance 0.25, without the final union."""
+    """ClipperOffset (6.4.2) AddPath(JT_ROUND, ET_CLOSEDPOLYGON) + the DoOffset half of Execute(delta), arc tolerance 0.25: the raw path."""
     P = [(int(x), int(y)) for x, y in pts]
     # AddPath: strip duplicate consecutive points (and a closing duplicate)
     Q = [P[0]]
@@ -329,6 +330,264 @@ def clipper_offset_round(pts: np.ndarray, delta: float) -> np.ndarray:
     return np.asarray(out, dtype=np.int64).reshape(-1, 2)
 
 
+# ------------------------------------------------------------------------------------------------------------------------------
+# ClipperOffset::Execute's closing pass: clpr.AddPaths(destPolys); clpr.Execute(ctUnion, solution, pftPositive, pftPositive).
+# The raw offset path crosses itself wherever the source polygon is concave (each concave join leaves an inverted loop, and the
+# offsets of the two walls of a notch narrower than 2*delta overlap completely); the union keeps the outline of the region whose
+# winding number is positive.  Restated here as: exact planar arrangement of the path (rational arithmetic) -> winding number of
+# every face -> outer boundary loop -> Clipper's integer rounding of the crossing points (IntersectPoint / TopX) -> FixupOutPolygon
+# (duplicates and collinear vertices dropped) -> BuildResult's emission order.  What is claimed is the CYCLIC vertex sequence and
+# its orientation; the start vertex follows the rule Clipper's sweep gives for an outline with a single top vertex (the vertex
+# after the top-most one comes first, the top-most -- right-most on a tie -- last) and is a modelling choice otherwise.
+# ------------------------------------------------------------------------------------------------------------------------------
+from fractions import Fraction as _Fr
+
+
+def _slopes_equal(p1, p2, p3) -> bool:
+    """ClipperLib::SlopesEqual(pt1, pt2, pt3) (exact integer arithmetic)."""
+    return (p1[1] - p2[1]) * (p2[0] - p3[0]) == (p1[0] - p2[0]) * (p2[1] - p3[1])
+
+
+def _addpath_cleanup(path):
+    """ClipperBase::AddPath, closed path: duplicate vertices and vertices collinear with their neighbours are removed until none is left."""
+    q = [(int(p[0]), int(p[1])) for p in path]
+    changed = True
+    while changed and len(q) >= 3:
+        changed = False
+        i = 0
+        while i < len(q) and len(q) >= 3:
+            a, b, c = q[i - 1], q[i], q[(i + 1) % len(q)]
+            if b == c or _slopes_equal(a, b, c):
+                del q[i]
+                changed = True
+                i = max(i - 1, 0)
+            else:
+                i += 1
+    return q if len(q) >= 3 else []
+
+
+class _Edge:
+    """TEdge fields IntersectPoint / TopX read (InitEdge2 + SetDx)."""
+    HORIZONTAL = -1.0e40
+
+    def __init__(self, a, b):
+        (ax, ay), (bx, by) = a, b
+        if ay >= by:
+            self.bot, self.top = (ax, ay), (bx, by)
+        else:
+            self.top, self.bot = (ax, ay), (bx, by)
+        dy = self.top[1] - self.bot[1]
+        self.dx = self.HORIZONTAL if dy == 0 else (self.top[0] - self.bot[0]) / dy
+
+    def top_x(self, y):
+        if y == self.top[1]:
+            return self.top[0]
+        return _round_half_away(self.bot[0] + self.dx * (y - self.bot[1]))
+
+
+def _clipper_intersect_point(sa, sb):
+    """ClipperLib::IntersectPoint for two crossing path edges (ProcessHorizontal's rule when one of them is horizontal)."""
+    e1, e2 = _Edge(*sa), _Edge(*sb)
+    H = _Edge.HORIZONTAL
+    if e1.dx == H or e2.dx == H:
+        h, o = (e1, e2) if e1.dx == H else (e2, e1)
+        return (o.top_x(h.bot[1]), h.bot[1])
+    if e2.dx < e1.dx:                      # Edge1 = the edge on the left below the crossing (BuildIntersectList's AEL order)
+        e1, e2 = e2, e1
+    if e1.dx == 0:
+        x = e1.bot[0]
+        b2 = e2.bot[1] - (e2.bot[0] / e2.dx)
+        return (x, _round_half_away(x / e2.dx + b2))
+    if e2.dx == 0:
+        x = e2.bot[0]
+        b1 = e1.bot[1] - (e1.bot[0] / e1.dx)
+        return (x, _round_half_away(x / e1.dx + b1))
+    b1 = e1.bot[0] - e1.bot[1] * e1.dx
+    b2 = e2.bot[0] - e2.bot[1] * e2.dx
+    q = (b2 - b1) / (e1.dx - e2.dx)
+    y = _round_half_away(q)
+    x = _round_half_away(e1.dx * q + b1) if abs(e1.dx) < abs(e2.dx) else _round_half_away(e2.dx * q + b2)
+    return (x, y)
+
+
+def _fixup_and_emit(outline):
+    """outline: the union's outer loop in emission direction (positive area).  Clipper holds it as a ring whose Next direction is the
+    reverse, with OutRec.Pts at the top vertex; FixupOutPolygon walks that ring from Pts, and BuildResult emits from Pts->Prev along Prev."""
+    m = len(outline)
+    if m < 3:
+        return []
+    k = min(range(m), key=lambda i: (outline[i][1], -outline[i][0]))
+    pt = [outline[(k - i) % m] for i in range(m)]           # Next order, Pts first
+    nxt = [(i + 1) % m for i in range(m)]
+    prv = [(i - 1) % m for i in range(m)]
+    pp, last_ok = 0, None
+    while True:
+        if prv[pp] == pp or prv[pp] == nxt[pp]:
+            return []
+        if pt[pp] == pt[nxt[pp]] or pt[pp] == pt[prv[pp]] or _slopes_equal(pt[prv[pp]], pt[pp], pt[nxt[pp]]):
+            last_ok = None
+            nxt[prv[pp]], prv[nxt[pp]] = nxt[pp], prv[pp]
+            pp = prv[pp]
+        elif pp == last_ok:
+            break
+        else:
+            if last_ok is None:
+                last_ok = pp
+            pp = nxt[pp]
+    out, p = [], prv[pp]
+    while True:
+        out.append(pt[p])
+        if p == pp:
+            break
+        p = prv[p]
+    return out
+
+
+def clipper_union_outline(path) -> List[Tuple[int, int]]:
+    """Outer polygon of Clipper's ctUnion / pftPositive of one closed integer path (see the block comment above)."""
+    P = _addpath_cleanup(path)
+    n = len(P)
+    if n < 3:
+        return []
+    seg = [(P[i], P[(i + 1) % n]) for i in range(n)]
+    cuts = [[_Fr(0), _Fr(1)] for _ in range(n)]
+    for i in range(n):
+        (ax, ay), (bx, by) = seg[i]
+        rx, ry = bx - ax, by - ay
+        for j in range(i + 1, n):
+            (cx, cy), (ex, ey) = seg[j]
+            if max(ax, bx) < min(cx, ex) or max(cx, ex) < min(ax, bx) or max(ay, by) < min(cy, ey) or max(cy, ey) < min(ay, by):
+                continue
+            sx, sy = ex - cx, ey - cy
+            wx, wy = cx - ax, cy - ay
+            d = rx * sy - ry * sx
+            if d != 0:
+                t, u = wx * sy - wy * sx, wx * ry - wy * rx
+                if d < 0:
+                    d, t, u = -d, -t, -u
+                if 0 <= t <= d and 0 <= u <= d:
+                    cuts[i].append(_Fr(t, d))
+                    cuts[j].append(_Fr(u, d))
+            elif wx * ry - wy * rx == 0:                     # collinear: the end points of each that fall inside the other
+                rr, ss = rx * rx + ry * ry, sx * sx + sy * sy
+                for (qx, qy) in seg[j]:
+                    t = (qx - ax) * rx + (qy - ay) * ry
+                    if 0 <= t <= rr:
+                        cuts[i].append(_Fr(t, rr))
+                for (qx, qy) in seg[i]:
+                    u = (qx - cx) * sx + (qy - cy) * sy
+                    if 0 <= u <= ss:
+                        cuts[j].append(_Fr(u, ss))
+    vid, vpt = {}, []
+
+    def vertex(x, y):
+        key = (x, y)
+        if key not in vid:
+            vid[key] = len(vpt)
+            vpt.append(key)
+        return vid[key]
+
+    mult, edir, eseg = {}, {}, {}                          # directed atomic edges: traversal count, integer direction, a source segment
+    for i in range(n):
+        (ax, ay), (bx, by) = seg[i]
+        rx, ry = bx - ax, by - ay
+        ts = sorted(set(cuts[i]))
+        ids = [vertex(ax + t * rx, ay + t * ry) for t in ts]
+        for u, v in zip(ids[:-1], ids[1:]):
+            if u == v:
+                continue
+            mult[(u, v)] = mult.get((u, v), 0) + 1
+            mult.setdefault((v, u), 0)
+            edir[(u, v)], edir[(v, u)] = (rx, ry), (-rx, -ry)
+            eseg.setdefault((u, v), i)
+            eseg.setdefault((v, u), i)
+    out_edges = {}
+    for (u, v) in mult:
+        out_edges.setdefault(u, []).append(v)
+
+    def angle_key(u):
+        import functools
+
+        def cmp(v1, v2):                                     # counter-clockwise from the +x axis, exact
+            (x1, y1), (x2, y2) = edir[(u, v1)], edir[(u, v2)]
+            h1 = 0 if (y1 > 0 or (y1 == 0 and x1 > 0)) else 1
+            h2 = 0 if (y2 > 0 or (y2 == 0 and x2 > 0)) else 1
+            if h1 != h2:
+                return h1 - h2
+            c = x1 * y2 - y1 * x2
+            return -1 if c > 0 else (1 if c < 0 else 0)
+        return functools.cmp_to_key(cmp)
+
+    pos = {}
+    for u, vs in out_edges.items():
+        vs.sort(key=angle_key(u))
+        for k, v in enumerate(vs):
+            pos[(u, v)] = k
+    # faces: the face on the left of u->v continues with the edge clockwise-next to v->u around v
+    face_of, faces = {}, []
+    for h in mult:
+        if h in face_of:
+            continue
+        cyc, g = [], h
+        while g not in face_of:
+            face_of[g] = len(faces)
+            cyc.append(g)
+            u, v = g
+            vs = out_edges[v]
+            g = (v, vs[(pos[(v, u)] - 1) % len(vs)])
+        faces.append(cyc)
+    # the unbounded face: every edge at the left-most (then lowest) vertex leaves into the right half plane, and the face holding the
+    # direction (-1, 0) there is on the left of the edge with the largest angle
+    u0 = min(range(len(vpt)), key=lambda i: vpt[i])
+    v0 = out_edges[u0][0]
+    for v in out_edges[u0][1:]:
+        (x1, y1), (x2, y2) = edir[(u0, v0)], edir[(u0, v)]
+        if x1 * y2 - y1 * x2 > 0:
+            v0 = v
+    outer = face_of[(u0, v0)]
+    wind = {outer: 0}
+    stack = [outer]
+    while stack:
+        f = stack.pop()
+        for (u, v) in faces[f]:
+            g = face_of[(v, u)]
+            if g not in wind:
+                wind[g] = wind[f] - (mult[(u, v)] - mult[(v, u)])   # the left of a forward edge is one turn up on its right
+                stack.append(g)
+    is_b = {h: (wind[face_of[h]] >= 1 and wind[face_of[(h[1], h[0])]] <= 0) for h in mult}
+    # boundary loops (interior on the left); at a vertex the next boundary edge is the first one counter-clockwise from the way back
+    best, seen = None, set()
+    for h0 in mult:
+        if not is_b[h0] or h0 in seen:
+            continue
+        loop, g = [], h0
+        while g not in seen:
+            seen.add(g)
+            loop.append(g)
+            u, v = g
+            vs = out_edges[v]
+            k = pos[(v, u)]
+            for s in range(1, len(vs) + 1):
+                cand = (v, vs[(k + s) % len(vs)])
+                if is_b[cand]:
+                    g = cand
+                    break
+        lo = min(vpt[u] for u, _ in loop)                    # the outer loop is the one through the left-most boundary vertex
+        if best is None or lo < best[0]:
+            best = (lo, loop)
+    if best is None:
+        return []
+    loop = best[1]
+    outline = []
+    for k, (u, v) in enumerate(loop):                        # vertex u: reached on the previous edge, left on this one
+        x, y = vpt[u]
+        if x.denominator == 1 and y.denominator == 1:
+            outline.append((int(x), int(y)))
+        else:
+            outline.append(_clipper_intersect_point(seg[eseg[loop[k - 1]]], seg[eseg[(u, v)]]))
+    return _fixup_and_emit(outline)
+
+
 def unclip(box: np.ndarray, unclip_ratio: float = 1.5) -> np.ndarray:
     """src/det/test.py:37-43 (shapely area / length in double; pyclipper JT_ROUND offset)."""
     p = box.astype(np.float64)
@@ -341,7 +600,8 @@ def unclip(box: np.ndarray, unclip_ratio: float = 1.5) -> np.ndarray:
     distance = area * unclip_ratio / length
     if distance <= 0:
         return np.zeros((0, 2), np.int64)
-    return clipper_offset_round(box, distance)
+    out = clipper_union_outline(clipper_offset_round(box, distance))
+    return np.asarray(out, dtype=np.int64).reshape(-1, 2)
 
 
 def db_postprocess(pred: np.ndarray, thresh=0.3, box_thresh=0.6, max_candidates=1000, unclip_ratio=1.5, min_area=10.0

@@ -1,0 +1,177 @@
+"""unclip's closing union (src/det/test.py:37-43: PyclipperOffset.Execute = raw round-join offset path, then Clipper's ctUnion /
+pftPositive self-union): the host C++ routine behind ocrvi_unclip_polygon against the independent Python statement
+oracle/dbpost_cpu.py:clipper_union_outline -- bit-exact vertex lists -- plus hand-derived known answers and the defining property
+(the outline bounds exactly the region where the raw path's winding number is positive).
+
+Parity with pyclipper itself is UNPINNED (not importable here, the reference holds no fixture).  What is claimed is the cyclic vertex
+sequence and orientation of Clipper's output; the start vertex is Clipper's for outlines with a single top vertex."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from oracle import dbpost_cpu as O  # noqa: E402
+from ocr_vi_invoice_amd import _lib as L  # noqa: E402
+
+
+def product_unclip(pts, delta):
+    lib = L.load()
+    pts = np.ascontiguousarray(pts, np.int32)
+    out = np.zeros((8192, 2), np.int32)
+    n = C.c_int(0)
+    L.check(lib.ocrvi_unclip_polygon(pts.ctypes.data, len(pts), float(delta), out.ctypes.data, 8192, C.byref(n)))
+    return [tuple(p) for p in out[:n.value].tolist()]
+
+
+def oracle_unclip(pts, delta):
+    return O.clipper_union_outline(O.clipper_offset_round(np.asarray(pts), delta))
+
+
+def both(pts, delta):
+    a, b = oracle_unclip(pts, delta), product_unclip(pts, delta)
+    assert a == b
+    return a
+
+
+def cyclic_equal(a, b):
+    if len(a) != len(b):
+        return False
+    if not a:
+        return True
+    return any(a[k:] + a[:k] == b for k in range(len(a)))
+
+
+def shoelace2(p):
+    return sum(p[i][0] * p[(i + 1) % len(p)][1] - p[(i + 1) % len(p)][0] * p[i][1] for i in range(len(p)))
+
+
+def winding(poly, xs, ys):
+    p = np.asarray(poly, float)
+    q = np.roll(p, -1, 0)
+    x0, y0, x1, y1 = p[:, 0:1], p[:, 1:2], q[:, 0:1], q[:, 1:2]
+    X, Y = xs[None, :], ys[None, :]
+    left = (x1 - x0) * (Y - y0) - (X - x0) * (y1 - y0)
+    return ((y0 <= Y) & (y1 > Y) & (left > 0)).sum(0) - ((y0 > Y) & (y1 <= Y) & (left < 0)).sum(0)
+
+
+def test_l_shape_known_answer():
+    """delta 10: Clipper's arc step is 2*pi / (pi / acos(1 - 0.25/10)) = 25.68 degrees, 4 steps per right angle, so the corner at (200, 0)
+    gives (200,-10) (204.3,-9.0) (207.8,-6.2) (209.7,-2.3) (210,0) -> rounded; the concave corner (100,100) leaves the three raw points
+    (100,110) (100,100) (110,100), which the union replaces by the crossing (110,110) of the offset edges y = 110 and x = 110; the
+    straight-through points (0,-10), (210,0), (200,110), ... are collinear and go.  Top-most, right-most vertex (200,-10) comes last."""
+    L_ = [(0, 0), (200, 0), (200, 100), (100, 100), (100, 200), (0, 200)]
+    assert both(L_, 10.0) == [
+        (204, -9), (208, -6), (210, -2), (210, 100), (209, 104), (206, 108), (202, 110), (110, 110), (110, 200), (109, 204), (106, 208),
+        (102, 210), (0, 210), (-4, 209), (-8, 206), (-10, 202), (-10, 0), (-9, -4), (-6, -8), (-2, -10), (200, -10)]
+    # the same polygon given in the other orientation (ClipperOffset::FixOrientations reverses it first)
+    assert cyclic_equal(both(L_[::-1], 10.0), both(L_, 10.0))
+
+
+def test_notched_rectangle_known_answer():
+    """400x200 rectangle with a 100-wide, 50-deep notch in its top side, delta 20: the notch survives as a 60-wide, 30-deep one whose
+    inner corners are the crossings (170,30) and (230,30) of the offset walls x = 170 / x = 230 with the offset floor y = 30."""
+    poly = [(0, 0), (150, 0), (150, 50), (250, 50), (250, 0), (400, 0), (400, 200), (0, 200)]
+    out = both(poly, 20.0)
+    s = set(out)
+    assert {(170, 30), (230, 30)} <= s
+    assert not s & {(150, 50), (250, 50), (150, 30), (170, 50), (230, 50), (250, 30)}      # the raw points of the two concave joins
+    assert shoelace2(out) > 0
+    xs, ys = [p[0] for p in out], [p[1] for p in out]
+    assert (min(xs), max(xs), min(ys), max(ys)) == (-20, 420, -20, 220)
+    # everything else is the raw path: replace each concave join's three points by its crossing, drop collinear points, compare cyclically
+    raw = [tuple(p) for p in O.clipper_offset_round(np.asarray(poly), 20.0).tolist()]
+    for tri, x in ((((170, 50), (150, 50), (150, 30)), (170, 30)), (((250, 30), (250, 50), (230, 50)), (230, 30))):
+        i = raw.index(tri[0])
+        assert tuple(raw[i:i + 3]) == tri
+        raw[i:i + 3] = [x]
+    assert cyclic_equal(O._addpath_cleanup(raw), out)
+
+
+def test_slit_narrower_than_twice_delta_closes():
+    """A 10-wide slit, delta 20: the offsets of its walls overlap, the union closes it; only the dent between the two corner arcs remains
+    (they cross above the slit's axis at y = -sqrt(20^2 - 5^2) = -19.4)."""
+    poly = [(0, 0), (195, 0), (195, 80), (205, 80), (205, 0), (400, 0), (400, 200), (0, 200)]
+    out = both(poly, 20.0)
+    near = [p for p in out if 180 <= p[0] <= 220 and p[1] < 100]
+    assert near and all(p[1] <= -17 for p in near)
+    assert any(p[0] in (199, 200, 201) and -20 <= p[1] <= -18 for p in near)          # the rounded crossing of the two arcs
+    xs, ys = [p[0] for p in out], [p[1] for p in out]
+    assert (min(xs), max(xs), min(ys), max(ys)) == (-20, 420, -20, 220)
+
+
+def test_convex_polygons_keep_the_raw_path():
+    """No concave vertex -> no crossing: the union only drops collinear points and re-bases the list (cyclic equality with the raw path)."""
+    from scipy.spatial import ConvexHull
+    rng = np.random.default_rng(11)
+    for _ in range(40):
+        cloud = rng.integers(0, 400, (int(rng.integers(5, 40)), 2)) * np.array([1, rng.integers(1, 3)]) // np.array([1, 2])
+        pts = cloud[ConvexHull(cloud).vertices].astype(np.int64)      # strictly convex, counter-clockwise
+        delta = float(rng.uniform(2, 30))
+        raw = O._addpath_cleanup(O.clipper_offset_round(pts, delta).tolist())
+        out = both(pts, delta)
+        assert cyclic_equal(raw, out)
+        k_top = min(range(len(out)), key=lambda i: (out[i][1], -out[i][0]))
+        assert k_top == len(out) - 1
+
+
+def _jagged(rng):
+    k = int(rng.integers(4, 40))
+    ang = np.sort(rng.uniform(0, 2 * np.pi, k))
+    rad = rng.uniform(10, 60, k)
+    sx, sy = rng.uniform(0.5, 4), rng.uniform(0.5, 1.5)
+    pts = np.stack([np.round(100 + sx * rad * np.cos(ang)), np.round(100 + sy * rad * np.sin(ang))], 1).astype(np.int64)
+    _, idx = np.unique(pts, axis=0, return_index=True)
+    return pts[np.sort(idx)]
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_product_matches_oracle_on_jagged_polygons(seed):
+    """Star-shaped polygons with deep concavities (both orientations), offsets from well below to well above the feature size."""
+    rng = np.random.default_rng(100 + seed)
+    n = 0
+    for t in range(120):
+        pts = _jagged(rng)
+        if len(pts) < 3:
+            continue
+        if t % 3 == 2:
+            pts = pts[::-1].copy()
+        out = both(pts, float(rng.uniform(0.6, 30)))
+        if out:
+            assert shoelace2(out) > 0 and len(out) >= 3
+            n += 1
+    assert n > 100
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_outline_bounds_the_positive_winding_region(seed):
+    """Defining property, checked with an independent point sampler: inside the outline <=> the raw offset path winds around the point
+    a positive number of times.  Only samples within one pixel of the outline may differ (Clipper rounds crossing points to integers)."""
+    rng = np.random.default_rng(200 + seed)
+    for _ in range(25):
+        pts = _jagged(rng)
+        if len(pts) < 4:
+            continue
+        delta = float(rng.uniform(1.5, 25))
+        raw = O.clipper_offset_round(pts, delta)
+        out = product_unclip(pts, delta)
+        assert len(out) >= 3
+        lo, hi = raw.min(0) - 2, raw.max(0) + 2
+        gx, gy = np.meshgrid(np.arange(lo[0], hi[0]) + 0.37, np.arange(lo[1], hi[1]) + 0.41)
+        xs, ys = gx.ravel(), gy.ravel()
+        bad = np.nonzero((winding(raw, xs, ys) > 0) != (winding(out, xs, ys) != 0))[0]
+        o = np.asarray(out, float)
+        d = np.roll(o, -1, 0) - o
+        for i in bad:
+            t = np.clip(((xs[i] - o[:, 0]) * d[:, 0] + (ys[i] - o[:, 1]) * d[:, 1]) / np.maximum((d ** 2).sum(1), 1e-9), 0, 1)
+            assert np.min(np.hypot(o[:, 0] + t * d[:, 0] - xs[i], o[:, 1] + t * d[:, 1] - ys[i])) <= 1.0
+        # and the bounding rectangle -- all the pipeline consumes (crop_image) -- is that of the raw path up to the rounding of crossings
+        assert np.all(np.abs(np.asarray(out).min(0) - raw.min(0)) <= 1) and np.all(np.abs(np.asarray(out).max(0) - raw.max(0)) <= 1)
+
+
+def test_degenerate_inputs():
+    assert both([(5, 5), (9, 9)], 3.0) == []                       # fewer than three points
+    both([(0, 0), (10, 0), (20, 0)], 3.0)                          # collinear input: whatever comes out, the two statements agree
+    assert len(both([(0, 0), (3, 0), (3, 3), (0, 3)], 0.7)) >= 4    # offset below one pixel
