@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void asf_scores_kernel(const T* __restrict__ p
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void asf_blend_kernel(const T* __restrict__ p2, const T* __restrict__ p3, const T* __restrict__ p4,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void asf_blend_kernel(const T* __restrict__ p2, const T* __restrict__ p3, const T* __restrict__ p4,
                                                         const T* __restrict__ p5, const float* __restrict__ s3, const float* __restrict__ s4,
                                                         const float* __restrict__ s5, const float* __restrict__ w, const float* __restrict__ bias,
                                                         T* __restrict__ out, int N, int H, int W) {
@@ -434,7 +434,9 @@ static void asf_launch(const void* p2, const void* p3, const void* p4, const voi
     }
     const size_t total = (size_t)N * H * W;
     const int grid = (int)std::min<size_t>(total / 64, 256 * 8);
-    hipLaunchKernelGGL(asf_blend_kernel<T>, dim3(grid), dim3(256), 0, s, (const T*)p2, (const T*)p3, (const T*)p4, (const T*)p5, s3, s4, s5, w, b,
+    static const int cap_lds = getenv("OCRVI_ASF_LDS") ? atoi(getenv("OCRVI_ASF_LDS")) : 0;   // experiment: occupancy cap through LDS
+    if (cap_lds > 65536) ensure_max_smem((const void*)asf_blend_kernel<T>, cap_lds);
+    hipLaunchKernelGGL(asf_blend_kernel<T>, dim3(grid), dim3(256), cap_lds, s, (const T*)p2, (const T*)p3, (const T*)p4, (const T*)p5, s3, s4, s5, w, b,
                        (T*)out, N, H, W);
 }
 
