@@ -323,6 +323,9 @@ __global__ __launch_bounds__(256) void asf_scores_kernel(const T* __restrict__ p
     }
 }
 
+// waves_per_eu(2, 2): left to itself hipcc allocates ~120 VGPRs for the fp16 / fp32 builds to reach 4 waves per SIMD and pays for it by
+// consuming the 25 loads of a pixel in small batches; this kernel lives on loads in flight per wave, not on waves (fp16 1374 -> 830 us,
+// fp32 1710 -> 1486 us for 16 pages; the bf16 build needs 239 VGPRs either way).
 template <typename T>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void asf_blend_kernel(const T* __restrict__ p2, const T* __restrict__ p3, const T* __restrict__ p4,
                                                         const T* __restrict__ p5, const float* __restrict__ s3, const float* __restrict__ s4,
@@ -434,9 +437,7 @@ static void asf_launch(const void* p2, const void* p3, const void* p4, const voi
     }
     const size_t total = (size_t)N * H * W;
     const int grid = (int)std::min<size_t>(total / 64, 256 * 8);
-    static const int cap_lds = getenv("OCRVI_ASF_LDS") ? atoi(getenv("OCRVI_ASF_LDS")) : 0;   // experiment: occupancy cap through LDS
-    if (cap_lds > 65536) ensure_max_smem((const void*)asf_blend_kernel<T>, cap_lds);
-    hipLaunchKernelGGL(asf_blend_kernel<T>, dim3(grid), dim3(256), cap_lds, s, (const T*)p2, (const T*)p3, (const T*)p4, (const T*)p5, s3, s4, s5, w, b,
+    hipLaunchKernelGGL(asf_blend_kernel<T>, dim3(grid), dim3(256), 0, s, (const T*)p2, (const T*)p3, (const T*)p4, (const T*)p5, s3, s4, s5, w, b,
                        (T*)out, N, H, W);
 }
 
