@@ -42,8 +42,8 @@ PROFILE_ROUND = "r02"
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--dtype", default=None, choices=["bf16", "f16", "f32"],
                     help="MFMA operand type of both models for the headline.  Default: f32 (the parity mode, whose CTC strings equal the CPU "
                          "reference's) followed by the --also mode; giving --dtype runs that one mode only")
