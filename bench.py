@@ -59,6 +59,9 @@ def parse():
     ap.add_argument("--boxes", default="detected", choices=["detected", "synthetic-gt"],
                     help="detected: crops come from DB post-processing of the (blended) detector map inside the timed region; "
                          "synthetic-gt: round-1 variant, ground-truth rectangles, no post-processing")
+    ap.add_argument("--post", choices=["host", "device"], default="host",
+                    help="DB post-processing: host = D2H of the whole map, everything on the host (as the reference); device = threshold + "
+                         "component labelling + box packing on the GPU, only mask / table / box values cross PCIe, host finishes")
     ap.add_argument("--post-threads", type=int, default=0, help="host threads for DB post-processing (0 = cores available / ranks, at most 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the fp32-mode re-run of the last step's crops (CER of the benchmarked dtype)")
@@ -170,6 +173,11 @@ class E2E:
             # two steps of pinned host maps in flight
             self.h_prob = [[torch.empty(p.shape, dtype=torch.float32).pin_memory() for p in self.prob] for _ in range(2)]
             self.ev_map = [[torch.cuda.Event() for _ in self.prob] for _ in range(2)]
+            self.dcomp = None
+            if getattr(a, "post", "host") == "device":
+                from ocr_vi_invoice_amd.pipeline import DBComponents
+                self.dcomp = [DBComponents(p.shape[0], a.height, a.width, self.dev, cap=4096, pack_frac=0.35, host_slots=2) for p in self.prob]
+                self.d2h_bytes = 0
         if self.rec is not None:
             rb = a.rec_batch
             self.d_rects = torch.zeros((rb, 5), dtype=torch.int32, device=self.dev)
@@ -191,6 +199,8 @@ class E2E:
         out = self.det(self.x[:n])                                             # all five maps, as DBNetPP.forward returns
         if self.detected:                                                      # synthetic text kernels over the random-weight map
             torch.add(self.kernel_add[i:i + n], out["binary"], alpha=0.25, out=self.prob[c])
+            if self.dcomp is not None:
+                self.dcomp[c].run(self.prob[c], self.pp.thresh)
         return out
 
     def _rec_batch(self):
@@ -301,9 +311,13 @@ class E2E:
             if self.detected:
                 for c in range(self.nchunk):
                     self.ev_map[step & 1][c].synchronize()
-                    maps = self.h_prob[step & 1][c]
-                    rects, cnt, _ = db_boxes_batch(maps.view(maps.shape[0], a.height, a.width), self.pp, 1.0, 1.0, (a.height, a.width),
-                                                   page_base=c * a.det_chunk, threads=self.post_threads, cap_per_page=256)
+                    if self.dcomp is not None:   # (no fallback map is handed over: an overflowing page raises instead of being guessed)
+                        rects, cnt, _ = self.dcomp[c].boxes(self.pp, None, 1.0, 1.0, (a.height, a.width), page_base=c * a.det_chunk,
+                                                            threads=self.post_threads, slot=step & 1, cap_per_page=256)
+                    else:
+                        maps = self.h_prob[step & 1][c]
+                        rects, cnt, _ = db_boxes_batch(maps.view(maps.shape[0], a.height, a.width), self.pp, 1.0, 1.0, (a.height, a.width),
+                                                       page_base=c * a.det_chunk, threads=self.post_threads, cap_per_page=256)
                     all_rects.append(rects)
                     counts.extend(int(v) for v in cnt)
                     if self.rec is not None:
@@ -337,7 +351,10 @@ class E2E:
                     else:
                         self._det_chunk(c)
                     if self.detected:
-                        self.h_prob[k][c].copy_(self.prob[c], non_blocking=True)
+                        if self.dcomp is not None:
+                            self.d2h_bytes += self.dcomp[c].copy_async(slot=k)
+                        else:
+                            self.h_prob[k][c].copy_(self.prob[c], non_blocking=True)
                         self.ev_map[k][c].record(self.s_det)
                 if not self.detected:
                     if not hasattr(self, "ev_det_done"):
@@ -475,6 +492,9 @@ def run_mode(args, dtype, dev, cdev, det_blob, rec_blob, images_u8, boxes, local
         prof = _lib.prof_report()
     out = {"dt": dt, "rects": last_rects, "texts": texts, "counts": counts, "prof": prof, "detected": pipe.detected,
            "post_threads": pipe.post_threads, "images": pipe.images}
+    if pipe.detected:   # bytes the post-processing stage pulls over PCIe per page (whole map, or mask + component table + box values)
+        out["d2h_bytes_per_page"] = (int(pipe.d2h_bytes / ((a.steps + a.warmup) * a.batch)) if getattr(pipe, "dcomp", None) is not None
+                                     else a.height * a.width * 4)
     pipe.close()
     return out
 
@@ -592,7 +612,8 @@ def main():
                        "weights": "seeded synthetic (no checkpoint ships)",
                        "launch": ("eager" if args.no_graph else "hipGraph replay") +
                                  (", one stream, one step at a time (--no-overlap)" if args.no_overlap else ", det stream || host post-processing || rec stream"),
-                       "post_process": {"in_timed_region": bool(m1["detected"]), "host_threads": m1["post_threads"]},
+                       "post_process": {"in_timed_region": bool(m1["detected"]), "host_threads": m1["post_threads"], "mode": args.post,
+                                        "d2h_bytes_per_page": m1.get("d2h_bytes_per_page")},
                        "parallelism": f"replicas x{world}, images sharded, no collective"},
         }
         if bcast_ms is not None:

@@ -145,6 +145,28 @@ int ocrvi_db_boxes_batch(const float* prob, int n_pages, int H, int W, float thr
                          float unclip_ratio, float min_area, double scale_w, double scale_h, int orig_h, int orig_w, int page_base,
                          int32_t* rects, float* scores, int cap_per_page, int32_t* counts, int threads);
 
+/* Device half of the same stage (the reference thresholds on the host, `pred[0] > self.thresh`, src/det/test.py:57,
+ * after copying the whole map, pipeline2.py:320).  prob: DEVICE float32 [n_pages,H,W] (W % 32 == 0).  Outputs, all DEVICE buffers:
+ *   mask_bits  uint32 [n_pages,H,W/32]   bit (x & 31) of word (x >> 5) = prob > thresh
+ *   comps      int32  [n_pages,cap,8]    per 8-connected component: x0, y0, x1, y1 (inclusive box), pixel count, root (index y*W+x of
+ *                                        its first pixel in raster order), sum of round(prob * 2^20) as uint64 in ints 6..7; row order
+ *                                        is arbitrary (sort by root for a canonical order)
+ *   counts     int32  [n_pages]          components found (may exceed cap: rows beyond cap are not written)
+ *   offsets    int64  [n_pages,cap+1]    start, in floats, of each component's box inside the page's packed region; [min(count,cap)] = total
+ *   packed     float32[n_pages,pack_cap] the probability values inside the component boxes, row-major per box, back to back (left
+ *                                        unwritten for a page whose total exceeds pack_cap).  offsets and packed may both be NULL.
+ * workspace: ocrvi_db_components_workspace_bytes(n_pages, H, W) bytes of device memory.  Asynchronous on `stream`. */
+size_t ocrvi_db_components_workspace_bytes(int n_pages, int H, int W);
+int ocrvi_db_components(int device, const float* prob, int n_pages, int H, int W, float thresh, uint32_t* mask_bits, int32_t* comps,
+                        int32_t* counts, int cap, long long* offsets, float* packed, long long pack_cap, void* workspace, void* stream);
+/* ocrvi_db_boxes_batch fed by HOST copies of ocrvi_db_components' outputs instead of the full maps: same results (the segmentation comes
+ * from mask_bits, the map is rebuilt inside the component boxes only, which is all box_score_fast reads).  skipped[page] = 1 (and
+ * counts[page] = 0) for a page whose table or boxes overflowed (count > cap or total > pack_cap): process that page from its full map. */
+int ocrvi_db_boxes_batch_sparse(const uint32_t* mask_bits, const int32_t* comps, const int32_t* comp_counts, int cap, const long long* offsets,
+                                const float* packed, long long pack_cap, int n_pages, int H, int W, float box_thresh, int max_candidates,
+                                float unclip_ratio, float min_area, double scale_w, double scale_h, int orig_h, int orig_w, int page_base,
+                                int32_t* rects, float* scores, int cap_per_page, int32_t* counts, int threads, int32_t* skipped);
+
 /* ------------------------------------------------------------------------------------------------
  * Kernel-level test/bench hooks (same kernels the models launch; used by tests/ and bench.py for
  * per-kernel parity and roofline timing).

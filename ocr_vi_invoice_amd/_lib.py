@@ -19,7 +19,7 @@ EXPORTS = [
     "ocrvi_det_create", "ocrvi_det_destroy", "ocrvi_det_workspace_bytes", "ocrvi_det_forward", "ocrvi_det_debug_features",
     "ocrvi_rec_create", "ocrvi_rec_destroy", "ocrvi_rec_workspace_bytes", "ocrvi_rec_forward", "ocrvi_rec_debug_features",
     "ocrvi_ctc_greedy", "ocrvi_normalize_u8", "ocrvi_resize_u8", "ocrvi_crop_resize_normalize", "ocrvi_db_postprocess", "ocrvi_db_boxes_batch",
-    "ocrvi_unclip_polygon",
+    "ocrvi_unclip_polygon", "ocrvi_db_components_workspace_bytes", "ocrvi_db_components", "ocrvi_db_boxes_batch_sparse",
     "ocrvi_test_deform_conv", "ocrvi_test_conv", "ocrvi_test_gemm", "ocrvi_test_attention", "ocrvi_test_mlp",
     "ocrvi_prof_enable", "ocrvi_prof_reset", "ocrvi_prof_report",
 ]
@@ -70,6 +70,11 @@ def load() -> C.CDLL:
     lib.ocrvi_resize_u8.argtypes = [i32, vp, i32, i32, vp, i32, i32, vp]
     lib.ocrvi_crop_resize_normalize.argtypes = [i32, vp, i32, i32, i32, i32p, i32, i32, i32, f32p, vp]
     lib.ocrvi_db_postprocess.argtypes = [vp, i32, i32, C.c_float, C.c_float, i32, C.c_float, C.c_float, vp, i32, vp, vp, i32, C.POINTER(i32)]
+    lib.ocrvi_db_components_workspace_bytes.argtypes = [i32, i32, i32]
+    lib.ocrvi_db_components_workspace_bytes.restype = sz
+    lib.ocrvi_db_components.argtypes = [i32, vp, i32, i32, i32, C.c_float, vp, vp, vp, i32, vp, vp, C.c_longlong, vp, vp]
+    lib.ocrvi_db_boxes_batch_sparse.argtypes = [vp, vp, vp, i32, vp, vp, C.c_longlong, i32, i32, i32, C.c_float, i32, C.c_float, C.c_float,
+                                                C.c_double, C.c_double, i32, i32, i32, vp, vp, i32, vp, i32, vp]
     lib.ocrvi_unclip_polygon.argtypes = [vp, i32, C.c_double, vp, i32, C.POINTER(i32)]
     lib.ocrvi_db_boxes_batch.argtypes = [vp, i32, i32, i32, C.c_float, C.c_float, i32, C.c_float, C.c_float, C.c_double, C.c_double, i32, i32, i32,
                                          vp, vp, i32, vp, i32]

@@ -61,7 +61,9 @@ void follow_border(signed char* f, int stride, int x0, int y0, bool is_hole, int
 // across calls (a fresh multi-megabyte allocation per page costs more in page faults than the scan itself).
 // `label_buf` overrides the per-thread buffer (the batch entry point keeps one per worker slot across calls: its threads are short-lived).
 thread_local std::vector<signed char>* label_buf = nullptr;
-void find_contours(const float* prob, float thresh, int H, int W, std::vector<std::vector<Pt>>& contours) {
+// `bits` (optional): the thresholded map as one bit per pixel, bit (x & 31) of word y * (W / 32) + (x >> 5) -- what the device half
+// (dbcomp.hip) hands over; the segmentation is then taken from it instead of `prob > thresh`.
+void find_contours(const float* prob, float thresh, int H, int W, std::vector<std::vector<Pt>>& contours, const uint32_t* bits = nullptr) {
     const int stride = W + 2;
     static thread_local std::vector<signed char> own;
     std::vector<signed char>& fbuf = label_buf ? *label_buf : own;
@@ -71,9 +73,18 @@ void find_contours(const float* prob, float thresh, int H, int W, std::vector<st
     memset(f + (size_t)(H + 1) * stride, 0, stride);
     for (int y = 0; y < H; ++y) {
         signed char* row = f + (size_t)(y + 1) * stride;
-        const float* pr = prob + (size_t)y * W;
         row[0] = 0;
-        for (int x = 0; x < W; ++x) row[x + 1] = pr[x] > thresh;
+        if (bits) {
+            const uint32_t* br = bits + (size_t)y * (W >> 5);
+            for (int xw = 0; xw < (W >> 5); ++xw) {
+                const uint32_t wv = br[xw];
+                if (!wv) { memset(row + 1 + 32 * xw, 0, 32); continue; }
+                for (int k = 0; k < 32; ++k) row[1 + 32 * xw + k] = (wv >> k) & 1;
+            }
+        } else {
+            const float* pr = prob + (size_t)y * W;
+            for (int x = 0; x < W; ++x) row[x + 1] = pr[x] > thresh;
+        }
         row[W + 1] = 0;
     }
     const int nbd = 2;
@@ -359,14 +370,14 @@ extern "C" int ocrvi_unclip_polygon(const int32_t* pts, int n_pts, double distan
     return OCRVI_OK;
 }
 
-extern "C" int ocrvi_db_postprocess(const float* prob, int H, int W, float thresh, float box_thresh, int max_candidates, float unclip_ratio,
-                                    float min_area, int32_t* points, int cap_points, int32_t* box_offsets, float* scores, int cap_boxes,
-                                    int* n_boxes) {
+static int db_postprocess_core(const float* prob, const uint32_t* bits, int H, int W, float thresh, float box_thresh, int max_candidates,
+                               float unclip_ratio, float min_area, int32_t* points, int cap_points, int32_t* box_offsets, float* scores,
+                               int cap_boxes, int* n_boxes) {
     using namespace ocrvi;
     OCRVI_CHECK(prob && points && box_offsets && scores && n_boxes && H > 0 && W > 0 && cap_points > 0 && cap_boxes > 0, OCRVI_EINVAL,
                 "db_postprocess: bad argument");
     std::vector<std::vector<Pt>> contours;
-    find_contours(prob, thresh, H, W, contours);
+    find_contours(prob, thresh, H, W, contours, bits);
     int nb = 0, np = 0;
     box_offsets[0] = 0;
     std::vector<Pt> approx, box;
@@ -401,20 +412,28 @@ extern "C" int ocrvi_db_postprocess(const float* prob, int H, int W, float thres
     return OCRVI_OK;
 }
 
+extern "C" int ocrvi_db_postprocess(const float* prob, int H, int W, float thresh, float box_thresh, int max_candidates, float unclip_ratio,
+                                    float min_area, int32_t* points, int cap_points, int32_t* box_offsets, float* scores, int cap_boxes,
+                                    int* n_boxes) {
+    return db_postprocess_core(prob, nullptr, H, W, thresh, box_thresh, max_candidates, unclip_ratio, min_area, points, cap_points, box_offsets,
+                               scores, cap_boxes, n_boxes);
+}
+
 // The host middle of the reference's per-image loop for a batch of pages (src/pipeline/pipeline2.py:320-343): DBPostProcessor on each
 // page's probability map -> boxes rescaled to the original image (int64 truncation of :324-328) -> the clamped bounding rectangle
 // crop_image slices (src/det/test.py:123-130).  Pages are independent, so they are spread over `threads` host threads (the reference
 // handles one page at a time in Python); everything stays in C so no interpreter lock is held.
-extern "C" int ocrvi_db_boxes_batch(const float* prob, int n_pages, int H, int W, float thresh, float box_thresh, int max_candidates,
-                                    float unclip_ratio, float min_area, double scale_w, double scale_h, int orig_h, int orig_w, int page_base,
-                                    int32_t* rects, float* scores, int cap_per_page, int32_t* counts, int threads) {
+namespace {
+struct PageView { const float* prob; const uint32_t* bits; bool ok; };
+
+// Shared body of the batch entries: page(pg, slot) hands over the map (and optionally its bit mask) of page pg for host thread `slot`.
+template <typename PageFn>
+int boxes_batch_impl(PageFn page, int n_pages, int H, int W, float thresh, float box_thresh, int max_candidates, float unclip_ratio,
+                     float min_area, double scale_w, double scale_h, int orig_h, int orig_w, int page_base, int32_t* rects, float* scores,
+                     int cap_per_page, int32_t* counts, int threads, int32_t* skipped) {
     using namespace ocrvi;
-    OCRVI_CHECK(prob && rects && counts && n_pages > 0 && H > 0 && W > 0 && cap_per_page > 0 && scale_w > 0 && scale_h > 0 && orig_h > 0 && orig_w > 0,
-                OCRVI_EINVAL, "db_boxes_batch: bad argument");
     std::atomic<int> next(0), failed(0);
-    static std::mutex pool_mu;                                  // one batch call at a time per process (it uses every core it is given anyway)
     static std::vector<std::vector<signed char>> label_pool;    // padded label images, kept across calls (page faults cost more than the scan)
-    std::lock_guard<std::mutex> lk(pool_mu);
     const int nt = std::max(1, std::min(threads, n_pages));
     if ((int)label_pool.size() < nt) label_pool.resize(nt);
     auto work = [&](int slot) {
@@ -425,12 +444,15 @@ extern "C" int ocrvi_db_boxes_batch(const float* prob, int n_pages, int H, int W
         for (;;) {
             const int pg = next.fetch_add(1);
             if (pg >= n_pages) break;
+            const PageView pv = page(pg, slot);
+            if (skipped) skipped[pg] = pv.ok ? 0 : 1;
+            if (!pv.ok) { counts[pg] = 0; continue; }
             int nb = 0, rc;
             size_t cap_pts = (size_t)4 * (H + W) + 4096;
             for (;;) {   // polygon vertex capacity is a guess: grow on OCRVI_ENOMEM
                 pts.resize(2 * cap_pts);
-                rc = ocrvi_db_postprocess(prob + (size_t)pg * H * W, H, W, thresh, box_thresh, max_candidates, unclip_ratio, min_area, pts.data(),
-                                          (int)cap_pts, offs.data(), sc.data(), cap_per_page, &nb);
+                rc = db_postprocess_core(pv.prob, pv.bits, H, W, thresh, box_thresh, max_candidates, unclip_ratio, min_area, pts.data(), (int)cap_pts,
+                                         offs.data(), sc.data(), cap_per_page, &nb);
                 if (rc != OCRVI_ENOMEM || cap_pts >= ((size_t)1 << 26)) break;
                 cap_pts *= 4;
             }
@@ -461,4 +483,56 @@ extern "C" int ocrvi_db_boxes_batch(const float* prob, int n_pages, int H, int W
     const int rc = failed.load();
     OCRVI_CHECK(rc == OCRVI_OK, rc, "db_boxes_batch: a page failed (%s)", ocrvi_last_error());
     return OCRVI_OK;
+}
+std::mutex g_batch_mu;   // one batch call at a time per process (it uses every core it is given anyway)
+}  // namespace
+
+extern "C" int ocrvi_db_boxes_batch(const float* prob, int n_pages, int H, int W, float thresh, float box_thresh, int max_candidates,
+                                    float unclip_ratio, float min_area, double scale_w, double scale_h, int orig_h, int orig_w, int page_base,
+                                    int32_t* rects, float* scores, int cap_per_page, int32_t* counts, int threads) {
+    using namespace ocrvi;
+    OCRVI_CHECK(prob && rects && counts && n_pages > 0 && H > 0 && W > 0 && cap_per_page > 0 && scale_w > 0 && scale_h > 0 && orig_h > 0 && orig_w > 0,
+                OCRVI_EINVAL, "db_boxes_batch: bad argument");
+    std::lock_guard<std::mutex> lk(g_batch_mu);
+    auto page = [&](int pg, int) { return PageView{prob + (size_t)pg * H * W, nullptr, true}; };
+    return boxes_batch_impl(page, n_pages, H, W, thresh, box_thresh, max_candidates, unclip_ratio, min_area, scale_w, scale_h, orig_h, orig_w,
+                            page_base, rects, scores, cap_per_page, counts, threads, nullptr);
+}
+
+// The same stage fed by the device half (ocrvi_db_components, dbcomp.hip): per page the 1-bit thresholded mask, the component table
+// (8 ints per component: x0, y0, x1, y1, count, root, sum) with its count, and the probability values inside the component boxes packed
+// back to back (offsets[id] = start of box id, offsets[n] = total).  The segmentation is taken from the mask; the map is rebuilt only
+// inside the component boxes -- every polygon box_score_fast looks at lies inside the box of the component its contour belongs to -- so
+// the results equal ocrvi_db_boxes_batch's on the full map.  A page whose table (count > cap) or boxes (total > pack_cap) overflowed is
+// not processed: skipped[page] = 1 and the caller falls back to the full map for it.
+extern "C" int ocrvi_db_boxes_batch_sparse(const uint32_t* mask_bits, const int32_t* comps, const int32_t* comp_counts, int cap,
+                                           const long long* offsets, const float* packed, long long pack_cap, int n_pages, int H, int W,
+                                           float box_thresh, int max_candidates, float unclip_ratio, float min_area, double scale_w, double scale_h,
+                                           int orig_h, int orig_w, int page_base, int32_t* rects, float* scores, int cap_per_page, int32_t* counts,
+                                           int threads, int32_t* skipped) {
+    using namespace ocrvi;
+    OCRVI_CHECK(mask_bits && comps && comp_counts && offsets && packed && rects && counts && skipped && cap > 0 && pack_cap > 0 && n_pages > 0 &&
+                    H > 0 && W > 0 && W % 32 == 0 && cap_per_page > 0 && scale_w > 0 && scale_h > 0 && orig_h > 0 && orig_w > 0,
+                OCRVI_EINVAL, "db_boxes_batch_sparse: bad argument");
+    std::lock_guard<std::mutex> lk(g_batch_mu);
+    static std::vector<std::vector<float>> map_pool;   // one page-sized map per host thread; only component boxes are ever (re)written or read
+    const int nt = std::max(1, std::min(threads, n_pages));
+    if ((int)map_pool.size() < nt) map_pool.resize(nt);
+    auto page = [&](int pg, int slot) {
+        const int n = comp_counts[pg];
+        const long long* o = offsets + (size_t)pg * (cap + 1);
+        if (n > cap || o[std::min(n, cap)] > pack_cap) return PageView{nullptr, nullptr, false};
+        std::vector<float>& m = map_pool[slot];
+        m.resize((size_t)H * W);
+        const float* src = packed + (size_t)pg * pack_cap;
+        for (int id = 0; id < n; ++id) {
+            const int32_t* c = comps + ((size_t)pg * cap + id) * 8;
+            const int x0 = c[0], y0 = c[1], w = c[2] - c[0] + 1, h = c[3] - c[1] + 1;
+            if (x0 < 0 || y0 < 0 || w <= 0 || h <= 0 || x0 + w > W || y0 + h > H) return PageView{nullptr, nullptr, false};   // corrupt table
+            for (int yy = 0; yy < h; ++yy) memcpy(m.data() + (size_t)(y0 + yy) * W + x0, src + o[id] + (size_t)yy * w, (size_t)w * sizeof(float));
+        }
+        return PageView{m.data(), mask_bits + (size_t)pg * H * (W >> 5), true};
+    };
+    return boxes_batch_impl(page, n_pages, H, W, 0.f, box_thresh, max_candidates, unclip_ratio, min_area, scale_w, scale_h, orig_h, orig_w, page_base,
+                            rects, scores, cap_per_page, counts, threads, skipped);
 }

@@ -163,6 +163,114 @@ def db_boxes_batch(prob_maps, post_processor: "DBPostProcessor", scale_w: float 
         np.concatenate([scores[i, :counts[i]] for i in range(n)], 0)
 
 
+class DBComponents:
+    """Device half of DB post-processing for a fixed page geometry: ``run(prob)`` thresholds DEVICE maps [n,H,W] and labels their
+    8-connected components (``ocrvi_db_components``), leaving in HBM the 1-bit mask, the component table and the probability values
+    inside the component boxes; ``to_host()`` (or the enqueue-only ``copy_async()``) copies those -- not the maps -- into one of
+    ``host_slots`` pinned buffer sets, and ``boxes()`` finishes the stage on the host (``ocrvi_db_boxes_batch_sparse``), falling back to
+    the full map for a page whose table or boxes overflowed.  Replaces the ``.cpu().numpy()`` of the whole map at pipeline2.py:320 plus the
+    thresholding at src/det/test.py:57."""
+
+    def __init__(self, n_pages: int, H: int, W: int, device="cuda:0", cap: int = 4096, pack_frac: float = 0.5, host_slots: int = 1):
+        assert W % 32 == 0, "page width must be a multiple of 32"
+        self.n, self.H, self.W, self.cap = n_pages, H, W, cap
+        self.dev = torch.device(device)
+        self.devi = self.dev.index or 0
+        self.pack_cap = int(H * W * pack_frac)
+        d = dict(device=self.dev)
+        self.bits = torch.empty((n_pages, H, W // 32), dtype=torch.int32, **d)
+        self.comps = torch.empty((n_pages, cap, 8), dtype=torch.int32, **d)
+        self.counts = torch.empty((n_pages,), dtype=torch.int32, **d)
+        self.offsets = torch.empty((n_pages, cap + 1), dtype=torch.int64, **d)
+        self.packed = torch.empty((n_pages, self.pack_cap), dtype=torch.float32, **d)
+        self.ws = torch.empty((_lib.load().ocrvi_db_components_workspace_bytes(n_pages, H, W),), dtype=torch.uint8, **d)
+        self._dev_bufs = (self.counts, self.offsets, self.comps, self.bits, self.packed)
+        self.host = [tuple(torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in self._dev_bufs) for _ in range(host_slots)]
+        self._select(0)
+
+    def _select(self, slot):
+        self.h_counts, self.h_offsets, self.h_comps, self.h_bits, self.h_packed = self.host[slot]
+
+    def run(self, prob: torch.Tensor, thresh: float, n_pages: int = None, stream=None):
+        n = n_pages or self.n
+        assert prob.is_cuda and prob.dtype == torch.float32 and prob.is_contiguous() and prob.numel() >= n * self.H * self.W and n <= self.n
+        st = stream if stream is not None else torch.cuda.current_stream(self.dev)
+        _lib.check(_lib.load().ocrvi_db_components(self.devi, prob.data_ptr(), n, self.H, self.W, float(thresh), self.bits.data_ptr(),
+                                                   self.comps.data_ptr(), self.counts.data_ptr(), self.cap, self.offsets.data_ptr(),
+                                                   self.packed.data_ptr(), self.pack_cap, self.ws.data_ptr(), st.cuda_stream))
+
+    def copy_async(self, slot: int = 0, n_pages: int = None, pack_floats: int = None) -> int:
+        """Enqueue-only: the tables, the mask and the first ``pack_floats`` (default: all) packed values of every page, on the current
+        stream, into host slot ``slot``.  Returns the bytes enqueued.  (A page that packed more than was copied is caught by ``boxes``.)"""
+        n = n_pages or self.n
+        k = self.pack_cap if pack_floats is None else min(int(pack_floats), self.pack_cap)
+        moved = 0
+        for h, dv in zip(self.host[slot][:4], self._dev_bufs[:4]):
+            h[:n].copy_(dv[:n], non_blocking=True)
+            moved += h[:n].numel() * h.element_size()
+        self.host[slot][4][:n, :k].copy_(self.packed[:n, :k], non_blocking=True)
+        self._copied = k
+        return moved + n * k * 4
+
+    def to_host(self, n_pages: int = None, slot: int = 0) -> int:
+        """Two-phase copy on the current stream: the small tables first, then only as much of each page's packed values as its table
+        says were written.  Returns the bytes that crossed PCIe."""
+        n = n_pages or self.n
+        self._select(slot)
+        moved = 0
+        for h, dv in zip(self.host[slot][:4], self._dev_bufs[:4]):
+            h[:n].copy_(dv[:n], non_blocking=True)
+            moved += h[:n].numel() * h.element_size()
+        torch.cuda.current_stream(self.dev).synchronize()
+        for pg in range(n):
+            c = int(self.h_counts[pg])
+            tot = int(self.h_offsets[pg, min(c, self.cap)])
+            if 0 < tot <= self.pack_cap and c <= self.cap:
+                self.h_packed[pg, :tot].copy_(self.packed[pg, :tot], non_blocking=True)
+                moved += tot * 4
+        torch.cuda.current_stream(self.dev).synchronize()
+        self._copied = self.pack_cap
+        return moved
+
+    def boxes(self, post_processor: "DBPostProcessor", prob: torch.Tensor = None, scale_w: float = 1.0, scale_h: float = 1.0,
+              orig_hw: Tuple[int, int] = None, page_base: int = 0, threads: int = 8, n_pages: int = None, slot: int = 0, cap_per_page: int = None):
+        """Host finish from the buffers of host slot ``slot``.  Returns what ``db_boxes_batch`` returns.  ``prob`` (the device maps) is
+        only read for pages that overflowed the table or the packed buffer (or the part of it that was copied)."""
+        n = n_pages or self.n
+        self._select(slot)
+        oh, ow = orig_hw if orig_hw is not None else (self.H, self.W)
+        cap = int(cap_per_page or post_processor.max_candidates)
+        rects, scores = np.empty((n, cap, 5), np.int32), np.empty((n, cap), np.float32)
+        counts, skipped = np.empty(n, np.int32), np.zeros(n, np.int32)
+        # pack_cap passed down = what was actually copied: a page with more packed values than that is skipped, not read past the copy
+        limit = min(getattr(self, "_copied", self.pack_cap), self.pack_cap)
+        lib = _lib.load()
+        if limit == self.pack_cap:
+            _lib.check(lib.ocrvi_db_boxes_batch_sparse(
+                self.h_bits.data_ptr(), self.h_comps.data_ptr(), self.h_counts.data_ptr(), self.cap, self.h_offsets.data_ptr(),
+                self.h_packed.data_ptr(), self.pack_cap, n, self.H, self.W, float(post_processor.box_thresh), int(post_processor.max_candidates),
+                float(post_processor.unclip_ratio), float(post_processor.min_area), float(scale_w), float(scale_h), int(oh), int(ow), int(page_base),
+                rects.ctypes.data, scores.ctypes.data, cap, counts.ctypes.data, int(threads), skipped.ctypes.data))
+        else:   # rows of the packed buffer are pack_cap apart but only `limit` floats of each are valid: one page per call
+            for pg in range(n):
+                _lib.check(lib.ocrvi_db_boxes_batch_sparse(
+                    self.h_bits[pg].data_ptr(), self.h_comps[pg].data_ptr(), self.h_counts[pg:].data_ptr(), self.cap, self.h_offsets[pg].data_ptr(),
+                    self.h_packed[pg].data_ptr(), limit, 1, self.H, self.W, float(post_processor.box_thresh), int(post_processor.max_candidates),
+                    float(post_processor.unclip_ratio), float(post_processor.min_area), float(scale_w), float(scale_h), int(oh), int(ow),
+                    int(page_base) + pg, rects[pg].ctypes.data, scores[pg].ctypes.data, cap, counts[pg:].ctypes.data, 1, skipped[pg:].ctypes.data))
+        for pg in np.nonzero(skipped)[0]:
+            if prob is None:
+                raise RuntimeError(f"db components: page {pg} overflowed the component table / packed buffer and no full map was given")
+            full = prob.reshape(-1, self.H, self.W)[pg:pg + 1].cpu()
+            r, c, sc = db_boxes_batch(full, post_processor, scale_w, scale_h, (oh, ow), page_base + int(pg), 1, cap_per_page=cap)
+            counts[pg] = c[0]
+            rects[pg, :c[0]] = r
+            scores[pg, :c[0]] = sc
+        keep = [rects[i, :counts[i]] for i in range(n)]
+        return (np.concatenate(keep, 0) if keep else np.empty((0, 5), np.int32)), counts.copy(), \
+            np.concatenate([scores[i, :counts[i]] for i in range(n)], 0)
+
+
 def rescale_boxes(boxes, scale_w: float, scale_h: float) -> List[np.ndarray]:
     """pipeline2.py:324-328: the in-place true-divide into the integer array truncates toward zero; then ``astype(int32)``."""
     out = []

@@ -630,6 +630,27 @@ def db_postprocess(pred: np.ndarray, thresh=0.3, box_thresh=0.6, max_candidates=
     return boxes, scores
 
 
+def components(prob: np.ndarray, thresh: float):
+    """Oracle for the device half (ocrvi_db_components): threshold, 8-connected components (the connectivity cv2.findContours follows),
+    per component (x0, y0, x1, y1, count, root, sum) with root = index y*W+x of its first pixel in raster order and
+    sum = sum of round(prob * 2^20); rows sorted by root.  Also the 1-bit mask packed as the device packs it."""
+    from scipy import ndimage as ndi
+    H, W = prob.shape
+    seg = prob > np.float32(thresh)
+    lab, n = ndi.label(seg, structure=np.ones((3, 3), int))
+    rows = []
+    q = np.rint(prob.astype(np.float32) * np.float32(1048576.0)).astype(np.int64)
+    for sl_i, sl in enumerate(ndi.find_objects(lab), start=1):
+        m = lab[sl] == sl_i
+        ys, xs = np.nonzero(m)
+        y0, x0 = sl[0].start, sl[1].start
+        root = int((ys[0] + y0) * W + xs[0] + x0)                 # np.nonzero is row-major: the first hit is the raster-first pixel
+        rows.append((x0, y0, sl[1].stop - 1, sl[0].stop - 1, int(m.sum()), root, int(q[sl][m].sum())))
+    rows.sort(key=lambda r: r[5])
+    bits = np.packbits(seg.reshape(H, W // 32, 32), axis=-1, bitorder="little").view(np.uint32).reshape(H, W // 32)
+    return rows, bits
+
+
 def rescale_and_rect(box: np.ndarray, scale_w: float, scale_h: float, img_h: int, img_w: int):
     """pipeline2.py:324-328 (in-place true-divide into the integer array truncates toward zero; then astype(int32)) followed by the
     rectangle crop_image slices (src/det/test.py:123-130: cv2.boundingRect of the integer points, clamped)."""

@@ -93,7 +93,8 @@ def test_strings_equal_reference_goldens(golden_dir, name, dt):
     assert m.decode_greedy(torch.from_numpy(g["x"]).cuda()) == [str(s) for s in g["strings"]]
 
 
-def test_bench_pipeline_small_f32_boxes_and_strings_match_the_oracle_chain():
+@pytest.mark.parametrize("post", ["host", "device"])   # whole map to the host / device threshold + components, host finish
+def test_bench_pipeline_small_f32_boxes_and_strings_match_the_oracle_chain(post):
     """configs[3] at reduced size through bench.py's own E2E class (fp32 mode): 6 pages 320x480, 5 lines each, detector -> blended map
     -> D2H -> ocrvi_db_boxes_batch -> crop + SVTRv2-base -> strings, pipelined on two streams + a host thread, against the oracle chain
     on the same inputs (oracle detector -> same blend -> oracle post-processing -> rects -> oracle pre-processing -> oracle recogniser);
@@ -110,7 +111,7 @@ def test_bench_pipeline_small_f32_boxes_and_strings_match_the_oracle_chain():
     spec.loader.exec_module(bench)
     H, W, B, lines = 320, 480, 6, 5
     args = argparse.Namespace(dtype="f32", workload="e2e", batch=B, lines=lines, det_chunk=4, rec_batch=16, height=H, width=W,
-                              boxes="detected", post_threads=3, no_graph=False)
+                              boxes="detected", post_threads=3, no_graph=False, post=post)
     det_sd, rec_sd = weights.make_det_state_dict(seed=1234), weights.make_rec_state_dict("base", seed=1234)
     imgs, gts = [], []
     for i in range(B):
