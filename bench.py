@@ -137,6 +137,9 @@ def shrink_box(x, y, w, h, unclip_ratio=1.6):
     return x + d, y + d, w - 2 * d, h - 2 * d
 
 
+_STREAMS = {}
+
+
 class E2E:
     """The timed region.  Everything on the device goes through libocrvi's C ABI; the host stage is ocrvi_db_boxes_batch."""
 
@@ -212,8 +215,13 @@ class E2E:
 
     def capture(self):
         torch, a = self.torch, self.args
-        self.s_det = torch.cuda.Stream(self.dev)
-        self.s_rec = self.s_det if getattr(a, "no_overlap", False) else torch.cuda.Stream(self.dev)
+        # one pair of streams per process, shared by the modes that run one after the other: every new HIP stream takes the next
+        # hardware queue round-robin, and a second pair ends up sharing queues (measured: the second mode lost its det || rec overlap,
+        # 134 instead of 110 ms per step)
+        if self.dev not in _STREAMS:
+            _STREAMS[self.dev] = (torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev))
+        self.s_det = _STREAMS[self.dev][0]
+        self.s_rec = self.s_det if getattr(a, "no_overlap", False) else _STREAMS[self.dev][1]
         self.g_det, self.g_rec = None, None
         if self.det is not None:
             with torch.cuda.stream(self.s_det):
@@ -243,25 +251,30 @@ class E2E:
         self.nstep = 0
 
     # ---- host side: post-process chunk by chunk, feed the recogniser, collect strings
-    def _enqueue_rec(self, rects, pending):
-        """rects: int32 [n,5]; full batches are launched, the remainder stays in `pending` (returned)."""
+    # Crops are batched ACROSS steps: a step's last, partial recogniser batch is not padded and launched but carried over and filled
+    # with the first crops of the next step (the pages stay resident, so its rectangles remain valid); only a flush -- the end of the
+    # timed region -- pads.  Every launched batch remembers which step each of its rows belongs to, and a step's result is emitted
+    # once all its rows are decoded, in row order.
+    def _feed(self, step, rects):
+        """Append step's rectangles to the carry-over and launch every full batch."""
         import numpy as np
-        torch, a = self.torch, self.args
-        rb = a.rec_batch
-        cat = rects if pending is None or not len(pending) else np.concatenate([pending, rects], 0)
-        launched = []
+        rb = self.args.rec_batch
+        ids = np.full(len(rects), step, np.int64)
+        self.pend_rects = rects if not len(self.pend_rects) else np.concatenate([self.pend_rects, rects], 0)
+        self.pend_steps = ids if not len(self.pend_steps) else np.concatenate([self.pend_steps, ids], 0)
         off = 0
-        while len(cat) - off >= rb:
-            launched.append(self._launch_rec(cat[off:off + rb], rb))
+        while len(self.pend_rects) - off >= rb:
+            self._launch_rec(self.pend_rects[off:off + rb], self.pend_steps[off:off + rb])
             off += rb
-        return cat[off:], launched
+        self.pend_rects, self.pend_steps = self.pend_rects[off:], self.pend_steps[off:]
 
-    def _launch_rec(self, rects, nvalid):
+    def _launch_rec(self, rects, steps):
         torch, a = self.torch, self.args
+        nvalid = len(rects)
         k = self.slot
         self.slot = (self.slot + 1) % len(self.h_rects)
         hr = self.h_rects[k].numpy()
-        hr[:nvalid] = rects[:nvalid]
+        hr[:nvalid] = rects
         if nvalid < a.rec_batch:
             hr[nvalid:] = 0                      # w = h = 0: the all-zero tensor of pipeline2.py:154-156; its string is dropped
         with torch.cuda.stream(self.s_rec):
@@ -273,15 +286,31 @@ class E2E:
             self.h_ids[k].copy_(self.g_ids, non_blocking=True)
             self.h_lens[k].copy_(self.g_lens, non_blocking=True)
             self.ev_rec[k].record(self.s_rec)
-        return k, nvalid
+        self.inflight.append((k, nvalid, steps.copy()))
 
-    def _strings(self, launched):
-        out = []
-        for k, nvalid in launched:
+    def _decode_until(self, step):
+        """Decode launched batches (oldest first) until every row of `step` has its string.  False if some are not launched yet."""
+        rec = self.open_steps[step]
+        while len(rec["texts"]) < rec["nrows"]:
+            if not self.inflight:
+                return False
+            k, nvalid, steps = self.inflight.popleft()
             self.ev_rec[k].synchronize()
             ids, lens = self.h_ids[k][:nvalid].tolist(), self.h_lens[k][:nvalid].tolist()
-            out.extend(self.rec.tokenizer.decode([row[:n] for row, n in zip(ids, lens)]))
-        return out
+            texts = self.rec.tokenizer.decode([row[:n] for row, n in zip(ids, lens)])
+            for st, t in zip(steps.tolist(), texts):
+                self.open_steps[st]["texts"].append(t)
+        return True
+
+    def _emit_complete(self, upto):
+        """Emit, in order, every open step < upto whose rows are all decoded."""
+        for st in sorted(self.open_steps):
+            if st >= upto:
+                break
+            if self.rec is not None and not self._decode_until(st):
+                break
+            rec = self.open_steps.pop(st)
+            self.results.put((rec["rects"], rec["texts"] if self.rec is not None else None, rec["counts"]))
 
     def _worker(self):
         try:
@@ -292,22 +321,27 @@ class E2E:
                 self.room.release()
 
     def _worker_loop(self):
+        import collections
         import numpy as np
         from ocr_vi_invoice_amd.pipeline import db_boxes_batch
         a = self.args
-        prev = None                              # (rects, launched batches) of the previous step: its strings are built one step late
+        self.pend_rects, self.pend_steps = np.zeros((0, 5), np.int32), np.zeros((0,), np.int64)
+        self.inflight, self.open_steps = collections.deque(), {}
         while True:
             job = self.jobs.get()
             if job is None:
                 break
-            if job == "flush":
-                if prev is not None:
-                    self.results.put((prev[0], self._strings(prev[1]), prev[2]))
-                    prev = None
+            if job == "flush":               # end of a timed region: the carried-over partial batch goes out padded, everything is decoded
+                if self.rec is not None and len(self.pend_rects):
+                    self._launch_rec(self.pend_rects, self.pend_steps)
+                    self.pend_rects, self.pend_steps = self.pend_rects[:0], self.pend_steps[:0]
+                self._emit_complete(1 << 62)
+                assert not self.open_steps and not self.inflight
                 self.results.put("flushed")
                 continue
             step = job
-            launched, pending, all_rects, counts = [], None, [], []
+            all_rects, counts = [], []
+            self.open_steps[step] = rec = {"rects": None, "texts": [], "counts": counts, "nrows": 1 << 62}
             if self.detected:
                 for c in range(self.nchunk):
                     self.ev_map[step & 1][c].synchronize()
@@ -321,8 +355,7 @@ class E2E:
                     all_rects.append(rects)
                     counts.extend(int(v) for v in cnt)
                     if self.rec is not None:
-                        pending, l2 = self._enqueue_rec(rects, pending)
-                        launched += l2
+                        self._feed(step, rects)
                 self.room.release()
             else:
                 rects = self.gt_rects
@@ -330,13 +363,11 @@ class E2E:
                 if self.rec is not None:
                     with self.torch.cuda.stream(self.s_rec):
                         self.s_rec.wait_event(self.ev_det_done[step & 1])
-                    pending, launched = self._enqueue_rec(rects, None)
+                    self._feed(step, rects)
                 self.room.release()
-            if self.rec is not None and pending is not None and len(pending):
-                launched.append(self._launch_rec(pending, len(pending)))
-            if prev is not None:                 # strings of step-1 while step's recogniser batches run
-                self.results.put((prev[0], self._strings(prev[1]), prev[2]))
-            prev = (np.concatenate(all_rects, 0) if all_rects else None, launched, counts)
+            rec["rects"] = np.concatenate(all_rects, 0) if all_rects else None
+            rec["nrows"] = len(rec["rects"]) if (rec["rects"] is not None and self.rec is not None) else 0
+            self._emit_complete(step)            # earlier steps whose tail rode on this step's first batch: their strings while this step's batches run
 
     def step(self):
         """Enqueue one step: the detector's chunks on its stream; everything downstream is driven by the worker thread."""
@@ -496,6 +527,13 @@ def run_mode(args, dtype, dev, cdev, det_blob, rec_blob, images_u8, boxes, local
         out["d2h_bytes_per_page"] = (int(pipe.d2h_bytes / ((a.steps + a.warmup) * a.batch)) if getattr(pipe, "dcomp", None) is not None
                                      else a.height * a.width * 4)
     pipe.close()
+    images = pipe.images
+    pipe.__dict__.clear()            # graphs, handles, pinned rings: give everything back before the next mode is set up
+    out["images"] = images
+    del pipe
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
     return out
 
 
