@@ -58,8 +58,12 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
 //   for c = 1 .. NCH-2:  [G1(c+1) | gelu_a(c)];  [G2(c-1) | gelu_b(c)];
 //   gelu_a(NCH-1);  [G2(NCH-2) | gelu_b(NCH-1)];  G2(NCH-1)
 // The weight stream is packed in exactly that order (pack_mlp_stream).
-template <typename T, int D, int WPS, int R>
-__global__ __launch_bounds__(256, WPS) void mlp_fused_kernel(const MlpParams p) {
+// TB = 16-token blocks per wave: 2 -> 4 waves of 32 tokens (one per SIMD, the whole register file each); 1 -> 8 waves of 16 tokens (two
+// per SIMD, 256 registers each: one wave's LDS / barrier waits and GELU fall under the other's MFMAs, at twice the LDS fragment traffic).
+template <typename T, int D, int WPS, int R, int TB = 2>
+__global__ __launch_bounds__(512 / TB, WPS) void mlp_fused_kernel(const MlpParams p) {
+    constexpr int NWV = 8 / TB, NT = 64 * NWV;   // waves, threads
+    constexpr int IPW = 16 / NWV;                  // DMA instructions per wave per 16-KiB piece
     constexpr int KS = D / 64;         // 128-byte K-steps of GEMM1
     constexpr int NP = D / 128;        // pieces per chunk and GEMM (W1: 2 K-steps x 64 rows; W2: 128 rows x 1 K-step)
     constexpr int NCH = 4 * D / 64;    // hidden chunks of 64
@@ -82,8 +86,8 @@ __global__ __launch_bounds__(256, WPS) void mlp_fused_kernel(const MlpParams p) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, g = lane >> 4;
     const bool next_ln = p.next_g != nullptr;
-    for (int i = tid; i < 4 * D; i += 256) c_b1[i] = p.b1[i];
-    for (int i = tid; i < D; i += 256) {
+    for (int i = tid; i < 4 * D; i += NT) c_b1[i] = p.b1[i];
+    for (int i = tid; i < D; i += NT) {
         c_b2[i] = p.b2[i];
         c_g[i] = p.ln_g[i];
         c_be[i] = p.ln_b[i];
@@ -109,12 +113,12 @@ __global__ __launch_bounds__(256, WPS) void mlp_fused_kernel(const MlpParams p) 
         const char* src = wbase + (size_t)prod_mod * UNIT;
         const unsigned dst = lds0 + prod_slot * UNIT + wave * 1024;
 #pragma unroll
-        for (int j = 0; j < 4 * NP; ++j) glds16(src + j * 4096, voff, __builtin_amdgcn_readfirstlane(dst + j * 4096));
+        for (int j = 0; j < IPW * NP; ++j) glds16(src + j * (NWV * 1024), voff, __builtin_amdgcn_readfirstlane(dst + j * (NWV * 1024)));
         prod_slot = prod_slot + 1 == R ? 0 : prod_slot + 1;
         prod_mod = prod_mod + 1 == UPT ? 0 : prod_mod + 1;
     };
     auto next_unit = [&]() -> const char* {  // wait for the oldest unit in flight, free the slot before it, keep the ring full
-        wait_vm_barrier<(PF - 1) * 4 * NP>();
+        wait_vm_barrier<(PF - 1) * IPW * NP>();
         issue_unit();
         const char* s = smem + cons_slot * UNIT;
         cons_slot = cons_slot + 1 == R ? 0 : cons_slot + 1;
@@ -127,12 +131,12 @@ __global__ __launch_bounds__(256, WPS) void mlp_fused_kernel(const MlpParams p) 
 
     for (int t = 0; t < my_tiles; ++t) {
         const int tile = (int)blockIdx.x + t * G;
-        const int tok0 = tile * 128 + wave * 32;
+        const int tok0 = tile * 128 + wave * (16 * TB);
         // ---- prologue: LayerNorm(x) of this wave's 32 tokens -> B-operand fragments.  Lane (lr, g) of token block b owns channels
         // 64 ks + 16 g .. + 16 of token tok0 + 16 b + lr for every K-step ks: its two 8-element halves are the two MFMA k-slots.
-        uint4 xf[KS][2][2];  // [ks][half][token block]
+        uint4 xf[KS][2][TB];  // [ks][half][token block]
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
+        for (int b = 0; b < TB; ++b) {
             float xv[KS][16];
             const int tok = min(tok0 + 16 * b + lr, p.M - 1);
             const float* xr = p.x + (size_t)tok * D + 16 * g;
@@ -178,37 +182,36 @@ __global__ __launch_bounds__(256, WPS) void mlp_fused_kernel(const MlpParams p) 
         // waits of the main loop start from the DMAs issued from here on (any older piece has landed)
         wait_vm_only<0>();
 
-        f32x4 acc2[NB2][2];
+        f32x4 acc2[NB2][TB];
 #pragma unroll
-        for (int a = 0; a < NB2; ++a) {
-            acc2[a][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            acc2[a][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-        f32x4 accA[4][2], accB[4][2];
-        uint32_t hfA[2][2][4], hfB[2][2][4];   // [k-slot half][token block][word]
+        for (int a = 0; a < NB2; ++a)
+#pragma unroll
+            for (int b = 0; b < TB; ++b) acc2[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 accA[4][TB], accB[4][TB];
+        uint32_t hfA[2][TB][4], hfB[2][TB][4];   // [k-slot half][token block][word]
+        constexpr int PH = 4 * TB;               // GELU pairs per k-slot half
 
         // bias + exact GELU of pair `PP` (0..15) of chunk c: half hh = PP >> 3 (the k-slot half of GEMM2 it lands in), token block
         // b = (PP >> 2) & 1, word jp = PP & 3  <->  hidden 16 (2 hh + (jp >> 1)) + 4 g + 2 (jp & 1) + {0, 1}
-        auto gelu_pair = [&](auto PP, const f32x4 (&acc)[4][2], uint32_t (&hf)[2][2][4], int c) {
-            constexpr int pp = decltype(PP)::value, hh = pp >> 3, b = (pp >> 2) & 1, jp = pp & 3, a = 2 * hh + (jp >> 1), r0 = 2 * (jp & 1);
+        auto gelu_pair = [&](auto PP, const f32x4 (&acc)[4][TB], uint32_t (&hf)[2][TB][4], int c) {
+            constexpr int pp = decltype(PP)::value, hh = pp / PH, b = (pp >> 2) % TB, jp = pp & 3, a = 2 * hh + (jp >> 1), r0 = 2 * (jp & 1);
             const float2 bv = *(const float2*)(c_b1 + 64 * c + 16 * a + 4 * g + r0);
             hf[hh][b][jp] = pack2<T>(gelu_erf(acc[a][b][r0] + bv.x), gelu_erf(acc[a][b][r0 + 1] + bv.y));
         };
         // GELU pairs [8 HALF + 8 k / GR, 8 HALF + 8 (k + 1) / GR) ride behind MFMA group k of a part
-        auto gelu_slice = [&](auto HALF, auto K, const f32x4 (&acc)[4][2], uint32_t (&hf)[2][2][4], int c) {
+        auto gelu_slice = [&](auto HALF, auto K, const f32x4 (&acc)[4][TB], uint32_t (&hf)[2][TB][4], int c) {
             constexpr int half = decltype(HALF)::value, k = decltype(K)::value;
             if constexpr (half >= 0) {
-                constexpr int lo = 8 * k / GR, hi = 8 * (k + 1) / GR;
-                static_for<hi - lo>([&](auto J) { gelu_pair(ICm<8 * half + lo + decltype(J)::value>{}, acc, hf, c); });
+                constexpr int lo = PH * k / GR, hi = PH * (k + 1) / GR;
+                static_for<hi - lo>([&](auto J) { gelu_pair(ICm<PH * half + lo + decltype(J)::value>{}, acc, hf, c); });
             }
         };
         // GEMM1 of one chunk into `dst` (its NP pieces come next in the stream); GELU half HALF (-1: none) of chunk c from `src` rides along
-        auto g1 = [&](f32x4 (&dst)[4][2], auto HALF, const f32x4 (&src)[4][2], uint32_t (&hf)[2][2][4], int c) {
+        auto g1 = [&](f32x4 (&dst)[4][TB], auto HALF, const f32x4 (&src)[4][TB], uint32_t (&hf)[2][TB][4], int c) {
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                dst[a][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                dst[a][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < TB; ++b) dst[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
             const char* const U1 = next_unit();
             static_for<NP>([&](auto P1) {
                 constexpr int p1 = decltype(P1)::value;
@@ -225,21 +228,20 @@ __global__ __launch_bounds__(256, WPS) void mlp_fused_kernel(const MlpParams p) 
                     constexpr int q = decltype(Q)::value;
                     if constexpr (q + 1 < 4) rd(ICm<q + 1>{});
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) {
-                        Mma<T>::half(wf[q & 1][a], xf[2 * p1 + (q >> 1)][q & 1][0], dst[a][0]);
-                        Mma<T>::half(wf[q & 1][a], xf[2 * p1 + (q >> 1)][q & 1][1], dst[a][1]);
-                    }
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < TB; ++b) Mma<T>::half(wf[q & 1][a], xf[2 * p1 + (q >> 1)][q & 1][b], dst[a][b]);
                     gelu_slice(HALF, ICm<4 * p1 + q>{}, src, hf, c);
                 });
             });
         };
         // GEMM2 of one chunk (h = `hin`) into acc2; GELU half HALF of chunk c from `src` into `hf` rides along
-        auto g2 = [&](const uint32_t (&hin)[2][2][4], auto HALF, const f32x4 (&src)[4][2], uint32_t (&hf)[2][2][4], int c) {
-            uint4 hv[2][2];
+        auto g2 = [&](const uint32_t (&hin)[2][TB][4], auto HALF, const f32x4 (&src)[4][TB], uint32_t (&hf)[2][TB][4], int c) {
+            uint4 hv[2][TB];
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int b = 0; b < 2; ++b) hv[h][b] = make_uint4(hin[h][b][0], hin[h][b][1], hin[h][b][2], hin[h][b][3]);
+                for (int b = 0; b < TB; ++b) hv[h][b] = make_uint4(hin[h][b][0], hin[h][b][1], hin[h][b][2], hin[h][b][3]);
             const char* const U2 = next_unit();
             static_for<NP>([&](auto P2) {
                 constexpr int p2 = decltype(P2)::value;
@@ -255,16 +257,15 @@ __global__ __launch_bounds__(256, WPS) void mlp_fused_kernel(const MlpParams p) 
                     constexpr int q = decltype(Q)::value;
                     if constexpr (q + 1 < 4) rd(ICm<q + 1>{});
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) {
-                        Mma<T>::half(wf[q & 1][a], hv[q >> 1][0], acc2[p2 * 8 + (q & 1) * 4 + a][0]);
-                        Mma<T>::half(wf[q & 1][a], hv[q >> 1][1], acc2[p2 * 8 + (q & 1) * 4 + a][1]);
-                    }
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < TB; ++b) Mma<T>::half(wf[q & 1][a], hv[q >> 1][b], acc2[p2 * 8 + (q & 1) * 4 + a][b]);
                     gelu_slice(HALF, ICm<4 * p2 + q>{}, src, hf, c);
                 });
             });
         };
-        auto gelu_only = [&](auto HALF, const f32x4 (&src)[4][2], uint32_t (&hf)[2][2][4], int c) {
-            static_for<8>([&](auto J) { gelu_pair(ICm<8 * decltype(HALF)::value + decltype(J)::value>{}, src, hf, c); });
+        auto gelu_only = [&](auto HALF, const f32x4 (&src)[4][TB], uint32_t (&hf)[2][TB][4], int c) {
+            static_for<PH>([&](auto J) { gelu_pair(ICm<PH * decltype(HALF)::value + decltype(J)::value>{}, src, hf, c); });
         };
         using NONE = ICm<-1>;
         g1(accA, NONE{}, accA, hfA, 0);                 // G1(0)
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(256, WPS) void mlp_fused_kernel(const MlpParams p) 
 
         // ---- epilogue: x <- x + fc2(..) + b2 (lane: channels 16 a + 4 g .. + 4 of token tok0 + 16 b + lr), then the optional next norm
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
+        for (int b = 0; b < TB; ++b) {
             const int tok = tok0 + 16 * b + lr;
             const bool ok = tok < p.M;
             float* xr = p.x + (size_t)(ok ? tok : 0) * D + 4 * g;
@@ -368,28 +369,31 @@ void pack_mlp_stream(const float* w1, const float* w2, int D, int dtype, std::ve
 
 bool mlp_fused_eligible(int dtype, int D) { return dtype != OCRVI_F32 && D % 128 == 0 && D >= 128 && D <= 384; }
 
-template <typename T, int D, int WPS, int R>
+template <typename T, int D, int WPS, int R, int TB = 2>
 static int launch_mlp(const MlpParams& p, hipStream_t s) {
     const int smem = R * (D / 128) * kPiece + (4 * D + 5 * D) * 4;
-    auto kern = mlp_fused_kernel<T, D, WPS, R>;
+    auto kern = mlp_fused_kernel<T, D, WPS, R, TB>;
     OCRVI_TRY(ensure_max_smem((const void*)kern, smem));
     int n_cu = 0;
     OCRVI_TRY(device_cus(&n_cu));
     const int ntiles = (p.M + 127) / 128;
     int grid = std::min(ntiles, n_cu * WPS);
     grid = cdiv(ntiles, cdiv(ntiles, grid));  // equal tile counts
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512 / TB), smem, s, p);
     OCRVI_HIP(hipGetLastError());
     return OCRVI_OK;
 }
 
 template <typename T> static int mlp_dt(const MlpParams& p, int D, hipStream_t s) {
+    // 8 waves of 16 tokens (two per SIMD) beat 4 waves of 32 (one per SIMD, the layout the register budget was first designed around)
+    // by 8-9 % at every D (MI355X, 256 crops: 223 -> 202, 284 -> 266, 271 -> 248 us): a wave's ring waits and its GELU stretches fall
+    // under the other wave's MFMAs, which outweighs reading every weight fragment from LDS twice as often.  OCRVI_MLP_TB=2: the old layout.
+    // (D = 128 would also fit two workgroups per CU, but that 256-register build of the 4-wave layout spilled and was measured wrong.)
+    static const bool tb2 = getenv("OCRVI_MLP_TB") && atoi(getenv("OCRVI_MLP_TB")) == 2;
     switch (D) {
-        // (D = 128 would fit two workgroups per CU, but its 256-register build spills inside the pipeline and was measured wrong on MI355X;
-        //  one workgroup per CU with the full register file is the tested configuration for every D)
-        case 128: return launch_mlp<T, 128, 1, 9>(p, s);    // ring: 9 units of 16 KiB
-        case 256: return launch_mlp<T, 256, 1, 4>(p, s);    //       4 units of 32 KiB
-        case 384: return launch_mlp<T, 384, 1, 3>(p, s);    //       3 units of 48 KiB
+        case 128: return tb2 ? launch_mlp<T, 128, 1, 9, 2>(p, s) : launch_mlp<T, 128, 1, 9, 1>(p, s);    // ring: 9 units of 16 KiB
+        case 256: return tb2 ? launch_mlp<T, 256, 1, 4, 2>(p, s) : launch_mlp<T, 256, 1, 4, 1>(p, s);    //       4 units of 32 KiB
+        case 384: return tb2 ? launch_mlp<T, 384, 1, 3, 2>(p, s) : launch_mlp<T, 384, 1, 3, 1>(p, s);    //       3 units of 48 KiB
     }
     set_error("mlp_fused: D=%d unsupported", D);
     return OCRVI_EINVAL;
