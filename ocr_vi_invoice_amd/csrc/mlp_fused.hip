@@ -9,7 +9,8 @@
 //     accumulators become, 16-bit packed, the B operand of GEMM2 (D x 64 slice of fc2) with no LDS round trip: an accumulator lane
 //     holds 4 consecutive hidden units of one token, and fc2's columns are permuted at pack time so that those are exactly the
 //     k-slots the lane owns in the next MFMA (cdna_hip_programming.md section 3, "An accumulator tile as the next MFMA's operand");
-//   * fc2 accumulates all D outputs of the 32 tokens of a wave in registers (D/2 VGPRs, one wave per SIMD owns the 512-entry file);
+//   * fc2 accumulates all D outputs of a wave's tokens in registers (D/4 VGPRs for the shipped 16 tokens per wave, two waves per SIMD;
+//     D/2 for the first layout, 32 tokens per wave with one wave per SIMD owning the 512-entry file -- template parameter TB);
 //   * the only streamed operand is the weights, identical for every tile: they are packed at load time into 16-KiB "pieces" in LDS
 //     image order and DMA'd (global_load_lds_dwordx4) into a ring that runs ahead across chunk and tile boundaries, counted vmcnt,
 //     one barrier per piece (the gemm_ring protocol with a deeper ring);
