@@ -36,8 +36,10 @@ template <> __device__ __forceinline__ f32x4 mfma16<f16_t>(const uint4& a, const
 
 // MAXT = number of 16-key tiles held in registers; MASK = false when N == 16*MAXT exactly (480 / 240 / 80 tokens at 48x320 input):
 // then no key masking is generated at all.
-template <typename T, int MAXT, bool MASK>
-__global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int N, int heads) {
+// NWV = waves per workgroup (they share the staged K / V^T): 8 for the fp32 480-key case, whose 123 KB of LDS allow one workgroup per CU --
+// with 4 waves that is one wave per SIMD and nothing to hide a wave's LDS latency and softmax behind.
+template <typename T, int MAXT, bool MASK, int NWV = 4>
+__global__ __launch_bounds__(NWV * 64) void attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int N, int heads) {
     constexpr int EPC = TypeInfo<T>::EPC;
     constexpr int KROW = AttnCfg<T>::KROW;
     constexpr int CH = KROW / 16;  // 16-byte chunks per K row
@@ -54,7 +56,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
     const T* base = qkv + (size_t)b * N * ld + h * 32;
 
     // ---- stage K (row-major, swizzled) and V^T
-    for (int idx = tid; idx < NP * CH; idx += 256) {
+    for (int idx = tid; idx < NP * CH; idx += NWV * 64) {
         const int key = idx / CH, ch = idx % CH;
         uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
         if (key < N) {
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
     const int lr = lane & 15, g = lane >> 4;
     const float c2 = 0.17677669529663687f * 1.4426950408889634f;  // 32^-0.5 * log2(e)
     const int NQ = (N + 15) >> 4;
-    for (int qt = wave; qt < NQ; qt += 4) {
+    for (int qt = wave; qt < NQ; qt += NWV) {
         const int q = qt * 16 + lr;
         const bool qok = q < N;
         f32x4 acc[MAXT];
@@ -382,7 +384,17 @@ template <typename T, int MAXT, bool MASK>
 static int launch_attn_m(const void* qkv, void* out, int B, int N, int heads, hipStream_t s) {
     constexpr int NP = ((MAXT + 1) / 2) * 32;
     const int smem = NP * AttnCfg<T>::KROW + 32 * AttnCfg<T>::vstride(NP);
-    auto kern = attention_kernel<T, MAXT, MASK>;
+    if constexpr (sizeof(T) == 4 && MAXT >= 30) {
+        static const bool w8 = !(getenv("OCRVI_ATTN_F32_W8") && atoi(getenv("OCRVI_ATTN_F32_W8")) == 0);   // A/B switch
+        if (w8) {
+            auto kern8 = attention_kernel<T, MAXT, MASK, 8>;
+            OCRVI_TRY(ensure_max_smem((const void*)kern8, smem));
+            hipLaunchKernelGGL(kern8, dim3(heads * B), dim3(512), smem, s, (const T*)qkv, (T*)out, N, heads);
+            OCRVI_HIP(hipGetLastError());
+            return OCRVI_OK;
+        }
+    }
+    auto kern = attention_kernel<T, MAXT, MASK, 4>;
     OCRVI_TRY(ensure_max_smem((const void*)kern, smem));
     hipLaunchKernelGGL(kern, dim3(heads * B), dim3(256), smem, s, (const T*)qkv, (T*)out, N, heads);
     OCRVI_HIP(hipGetLastError());
