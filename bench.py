@@ -649,7 +649,8 @@ def main():
                        "crops_per_step_rank0": n_crops, "boxes_per_page_min_max": [min(counts), max(counts)] if counts else None,
                        "weights": "seeded synthetic (no checkpoint ships)",
                        "launch": ("eager" if args.no_graph else "hipGraph replay") +
-                                 (", one stream, one step at a time (--no-overlap)" if args.no_overlap else ", det stream || host post-processing || rec stream"),
+                                 (", one stream, one step at a time (--no-overlap)" if args.no_overlap else
+                                  ", det stream || host post-processing || rec stream; recogniser batches filled across steps, one padded batch at the flush"),
                        "post_process": {"in_timed_region": bool(m1["detected"]), "host_threads": m1["post_threads"], "mode": args.post,
                                         "d2h_bytes_per_page": m1.get("d2h_bytes_per_page")},
                        "parallelism": f"replicas x{world}, images sharded, no collective"},
