@@ -10,6 +10,7 @@
 #include "gemm_ring.h"
 #include "gconv32.h"
 #include "dcn_pipe.h"
+#include "offs_conv.h"
 
 namespace ocrvi {
 
@@ -188,6 +189,7 @@ int launch_conv(const ConvParams& p_in, int amode, hipStream_t stream) {
     if constexpr (sizeof(T) == 2) {
         if (gconv32_eligible(p, amode, 2)) return launch_gconv32<T>(p, stream);
     }
+    if (offs_conv_eligible(p, amode, TypeInfo<T>::dtype)) return launch_offs_conv<T>(p, stream);
     if (gemm_ring_eligible(p, amode, TypeInfo<T>::dtype)) return launch_gemm_ring<T>(p, amode, stream);
     switch (amode) {
         case AM_CONV1: return launch_mode<T, AM_CONV1>(p, stream);
