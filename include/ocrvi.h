@@ -171,6 +171,11 @@ int ocrvi_db_boxes_batch_sparse(const uint32_t* mask_bits, const int32_t* comps,
  * Kernel-level test/bench hooks (same kernels the models launch; used by tests/ and bench.py for
  * per-kernel parity and roofline timing).
  * ------------------------------------------------------------------------------------------------ */
+/* The 27-channel offset / mask conv of DeformableConv2d alone (dcn.py:42-46: self.offset_conv, then sigmoid on channels 18..26): x float32
+ * NCHW [N,C,H,W] (device), weight float32 host [27,C,3,3], bias host [27]; pad 1, stride 1 or 2; out DEVICE float32 [N,Ho,Wo,32]
+ * (0..17 offsets, 18..26 mask, 27..31 zero).  Test hook: allocates and synchronises internally. */
+int ocrvi_test_offset_conv(int device, int dtype, const float* x, const float* weight_host, const float* bias_host, int N, int C, int H, int W,
+                           int stride, float* out, int iters, float* avg_ms);
 /* Modulated deformable 3x3 conv, pad 1, dil 1 (torchvision.ops.deform_conv2d as called at dcn.py:48-57) with
  * a fused per-channel bias (+ optional ReLU) epilogue.  x float32 NCHW [N,C,H,W]; offset [N,18,Ho,Wo];
  * mask [N,9,Ho,Wo] (already sigmoided); weight float32 host [Co,C,3,3]; bias float32 host [Co] or NULL;

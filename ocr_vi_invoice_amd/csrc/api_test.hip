@@ -142,6 +142,32 @@ extern "C" int ocrvi_test_conv(int device, int dtype, const float* x, const floa
     return OCRVI_OK;
 }
 
+// The 27-channel offset / mask conv of DeformableConv2d on its own (dcn.py:42-46): 3x3, pad 1, stride 1 or 2; out = device float32
+// [N, Ho, Wo, 32]: channels 0..17 offsets, 18..26 sigmoid(mask logits), 27..31 zero -- the layout the deformable conv kernels consume.
+extern "C" int ocrvi_test_offset_conv(int device, int dtype, const float* x, const float* weight_host, const float* bias_host, int N, int C,
+                                      int H, int W, int stride, float* out, int iters, float* avg_ms) {
+    OCRVI_CHECK(x && weight_host && bias_host && out && (stride == 1 || stride == 2) && N > 0 && C > 0, OCRVI_EINVAL, "test_offset_conv: bad argument");
+    OCRVI_HIP(hipSetDevice(device));
+    Scratch sc;
+    OCRVI_TRY(sc.init());
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    DeviceStore st;
+    ConvLayer L;
+    PackedConv pc = pack_conv(weight_host, bias_host, 27, C, 3, 3, 1, AM_CONV3, dtype);
+    OCRVI_TRY(upload_packed(st, pc, AM_CONV3, &L));
+    void* xn = nullptr;
+    OCRVI_TRY(sc.alloc((size_t)N * H * W * C * dtype_size(dtype), &xn));
+    OCRVI_TRY(to_nhwc(dtype, x, xn, N, C, H * W, sc.s));
+    Runner r(dtype, sc.s, (void*)256, 0);
+    Tensor tx; tx.p = xn; tx.n = N; tx.h = H; tx.w = W; tx.c = C;
+    Tensor ty; ty.p = out; ty.n = N; ty.h = Ho; ty.w = Wo; ty.c = 32; ty.f32 = true;
+    ConvOpts o;
+    o.sh = o.sw = stride; o.pad = 1; o.store_mode = ST_DCN_OFFS;
+    OCRVI_TRY(timed(sc, iters, avg_ms, [&]() { return conv(r, L, tx, ty, o); }));
+    OCRVI_HIP(hipStreamSynchronize(sc.s));
+    return OCRVI_OK;
+}
+
 extern "C" int ocrvi_test_gemm(int device, int dtype, const float* a, const float* weight_host, const float* bias_host, const float* res, int M,
                                int K, int N, int act, int res_post, int out_f32, float* out, int iters, float* avg_ms) {
     OCRVI_CHECK(a && weight_host && out && M > 0 && K > 0 && N > 0, OCRVI_EINVAL, "test_gemm: bad argument");

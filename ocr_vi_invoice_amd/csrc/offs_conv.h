@@ -195,7 +195,8 @@ static int launch_offs_conv(const ConvParams& p, hipStream_t stream) {
         const int cost = cdiv(tiles, n_cu) * (th + 2);
         if (cost < best_cost) { best = th; best_cost = cost; }
     }
-    static const int force = getenv("OCRVI_OFFS_TH") ? atoi(getenv("OCRVI_OFFS_TH")) : 0;   // experiment knob
+    const char* fe = getenv("OCRVI_OFFS_TH");           // test / experiment knob (read per launch so that a test can sweep it)
+    const int force = fe ? atoi(fe) : 0;
     if (force == 16 || force == 8 || force == 4) best = force;
     if (best == 16) return launch_offs_conv_t<T, 1, 16>(p, n_cu, stream);
     if (best == 8) return launch_offs_conv_t<T, 1, 8>(p, n_cu, stream);

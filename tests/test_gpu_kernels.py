@@ -2,6 +2,7 @@
 on the CPU / the oracle.  fp32-MFMA mode must match to 1e-4-ish; bf16 / fp16 modes are checked against an
 error budget relative to the output scale (stated per test)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -287,3 +288,46 @@ def test_mlp_fused_kernel(M, D, mode, dt):
     if want_xn is not None:
         assert _rel_err(outs[0][1], want_xn.float()) < 1.5 * TOL[dt]
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("case", [
+    # (N, C, H, W, stride): ragged maps (partial 16-pixel blocks, fewer rows than a tile, single pixels) and the detector's own shapes
+    (2, 128, 9, 11, 1), (1, 256, 20, 35, 1), (3, 128, 5, 40, 2), (1, 512, 1, 1, 1), (2, 256, 17, 33, 2), (1, 128, 30, 40, 1),
+    (1, 512, 8, 12, 2), (1, 256, 64, 16, 1),
+])
+def test_offset_conv_kernel(case, dt):
+    """dcn.py:42-46: the 27-channel 3x3 offset / mask conv (direct halo-tile kernel, offs_conv.h) against torch conv2d in fp64 -> fp32:
+    offsets (channels 0..17) raw, mask (18..26) through the sigmoid, padding channels zero; every tile height the launcher can pick."""
+    L = _lib()
+    lib = L.load()
+    N, Cc, H, W, st = case
+    g = torch.Generator().manual_seed(N * 1000 + Cc + H * 7 + W + st)
+    x = torch.randn(N, Cc, H, W, generator=g)
+    w = torch.randn(27, Cc, 3, 3, generator=g) / (9 * Cc) ** 0.5
+    b = torch.randn(27, generator=g) * 0.3
+    Ho, Wo = (H - 1) // st + 1, (W - 1) // st + 1
+    if dt != "f32":      # the 16-bit kernels see operands rounded to their type; compare against that
+        td = torch.bfloat16 if dt == "bf16" else torch.float16
+        xr, wr = x.to(td).double(), w.to(td).double()
+    else:
+        xr, wr = x.double(), w.double()
+    ref = torch.nn.functional.conv2d(xr, wr, b.double(), stride=st, padding=1)
+    ref = torch.cat([ref[:, :18], torch.sigmoid(ref[:, 18:])], 1).permute(0, 2, 3, 1).float()
+    wh, bh = np.ascontiguousarray(w.numpy()), np.ascontiguousarray(b.numpy())
+    outs = []
+    for th in ("16", "8", "4"):
+        os.environ["OCRVI_OFFS_TH"] = th      # force the tile height (stride 1; stride 2 has one)
+        out = torch.full((N, Ho, Wo, 32), float("nan"), device="cuda")
+        ms = C.c_float(0)
+        L.check(lib.ocrvi_test_offset_conv(0, DT[dt], x.cuda().data_ptr(), wh.ctypes.data, bh.ctypes.data, N, Cc, H, W, st, out.data_ptr(), 1,
+                                           C.byref(ms)))
+        outs.append(out.cpu())
+    os.environ.pop("OCRVI_OFFS_TH", None)
+    out = outs[0]
+    for o2 in outs[1:]:      # tile heights only regroup pixels: every output element sees the same sums in the same order
+        assert torch.equal(outs[0], o2)
+    assert torch.isfinite(out).all() and float(out[..., 27:].abs().max()) == 0.0
+    tol = 2e-5 if dt == "f32" else 2e-3      # fp32 accumulation of exactly representable products; the sigmoid compresses further
+    err = float((out[..., :27] - ref).abs().max())
+    assert err < tol, err
