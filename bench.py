@@ -34,7 +34,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}  # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3, "f16x2": 157.3}  # dense MFMA peaks, MI355X_MICROARCH.md (f16x2: see roofline_of)
 PEAK_HBM_GBS = 8000.0
 PROFILE_ROUND = "r02"
 
@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--dtype", default=None, choices=["bf16", "f16", "f32"],
+    ap.add_argument("--dtype", default=None, choices=["bf16", "f16", "f32", "f16x2"],
                     help="MFMA operand type of both models for the headline.  Default: f32 (the parity mode, whose CTC strings equal the CPU "
                          "reference's) followed by the --also mode; giving --dtype runs that one mode only")
     ap.add_argument("--also", default="f16", choices=["f16", "bf16", "none"],

@@ -26,8 +26,13 @@ extern "C" {
 #define OCRVI_ENOMEM (-3) /* workspace too small */
 #define OCRVI_EBLOB (-4)  /* weight blob malformed or a tensor is missing / has the wrong shape */
 
-/* Arithmetic type the MFMA kernels compute in (accumulation is always fp32). */
-typedef enum { OCRVI_F32 = 0, OCRVI_BF16 = 1, OCRVI_F16 = 2 } ocrvi_dtype;
+/* Arithmetic type the MFMA kernels compute in (accumulation is always fp32).
+ * OCRVI_F32   fp32 operands on v_mfma_f32_16x16x4_f32: bit for bit an fp32 fmaf chain (what the reference's CPU path computes in).
+ * OCRVI_F16X2 fp32-equivalent operands on the 16-bit matrix pipe: every GEMM operand element is stored as two fp16 halves
+ *             x = hi + lo (>= 22 significant bits, weights scaled by a power of two per layer) and every product is formed from the
+ *             partial products hi hi + hi lo + lo hi + lo lo in fp32 accumulators; same API, same fp32 inputs and outputs.
+ * OCRVI_BF16 / OCRVI_F16  plain 16-bit operands (throughput modes). */
+typedef enum { OCRVI_F32 = 0, OCRVI_BF16 = 1, OCRVI_F16 = 2, OCRVI_F16X2 = 3 } ocrvi_dtype;
 
 const char* ocrvi_last_error(void);
 /* ABI version of this header (bumped on any signature change). */

@@ -9,9 +9,11 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libocrvi.so")
 
-OCRVI_F32, OCRVI_BF16, OCRVI_F16 = 0, 1, 2
+OCRVI_F32, OCRVI_BF16, OCRVI_F16, OCRVI_F16X2 = 0, 1, 2, 3
 DTYPES = {"f32": OCRVI_F32, "fp32": OCRVI_F32, "float32": OCRVI_F32, "bf16": OCRVI_BF16, "bfloat16": OCRVI_BF16,
-          "f16": OCRVI_F16, "fp16": OCRVI_F16, "float16": OCRVI_F16}
+          "f16": OCRVI_F16, "fp16": OCRVI_F16, "float16": OCRVI_F16,
+          # fp32-equivalent arithmetic on the 16-bit matrix pipe: every operand kept as two fp16 halves (include/ocrvi.h)
+          "f16x2": OCRVI_F16X2}
 ABI_VERSION = 1
 
 EXPORTS = [
@@ -121,7 +123,7 @@ def dtype_code(dtype) -> int:
     try:
         return DTYPES[str(dtype).replace("torch.", "")]
     except KeyError:
-        raise ValueError(f"unsupported compute dtype {dtype!r}; choose from f32, bf16, f16") from None
+        raise ValueError(f"unsupported compute dtype {dtype!r}; choose from f32, f16x2, bf16, f16") from None
 
 
 def ptr(t) -> Optional[int]:

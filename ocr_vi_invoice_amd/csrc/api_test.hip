@@ -15,7 +15,7 @@ __global__ void nchw_f32_to_nhwc_kernel(const float* __restrict__ x, T* __restri
         const int c = (int)(i % C);
         const size_t t = i / C;
         const int p = (int)(t % HW), n = (int)(t / HW);
-        y[i] = from_f32<T>(x[((size_t)n * C + c) * HW + p]);
+        store_elem<T>(y, i, x[((size_t)n * C + c) * HW + p]);
     }
 }
 int to_nhwc(int dt, const float* x, void* y, int N, int C, int HW, hipStream_t s) {
@@ -25,6 +25,7 @@ int to_nhwc(int dt, const float* x, void* y, int N, int C, int HW, hipStream_t s
         case OCRVI_F32: hipLaunchKernelGGL(nchw_f32_to_nhwc_kernel<float>, dim3(grid), dim3(256), 0, s, x, (float*)y, N, C, HW); break;
         case OCRVI_BF16: hipLaunchKernelGGL(nchw_f32_to_nhwc_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, x, (bf16_t*)y, N, C, HW); break;
         case OCRVI_F16: hipLaunchKernelGGL(nchw_f32_to_nhwc_kernel<f16_t>, dim3(grid), dim3(256), 0, s, x, (f16_t*)y, N, C, HW); break;
+        case OCRVI_F16X2: hipLaunchKernelGGL(nchw_f32_to_nhwc_kernel<f16x2_t>, dim3(grid), dim3(256), 0, s, x, (f16x2_t*)y, N, C, HW); break;
         default: set_error("unknown dtype %d", dt); return OCRVI_EINVAL;
     }
     OCRVI_HIP(hipGetLastError());
@@ -174,7 +175,7 @@ extern "C" int ocrvi_test_gemm(int device, int dtype, const float* a, const floa
     OCRVI_HIP(hipSetDevice(device));
     Scratch sc;
     OCRVI_TRY(sc.init());
-    const bool f32o = out_f32 || dtype == OCRVI_F32;
+    const bool f32o = out_f32 || dtype == OCRVI_F32;   // (f16x2: its own 4-byte format unless out_f32)
     DeviceStore st;
     ConvLayer L;
     PackedConv pc = pack_conv(weight_host, bias_host, N, K, 1, 1, 1, AM_CONV1, dtype);

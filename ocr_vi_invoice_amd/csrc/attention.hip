@@ -23,6 +23,7 @@ template <> struct AttnCfg<bf16_t> {
     static constexpr __host__ __device__ int vstride(int NP) { return (NP * 2 + 255) / 256 * 256 + 16; }  // = 16 B mod 256 B: conflict-free b64 column reads
 };
 template <> struct AttnCfg<f16_t> : AttnCfg<bf16_t> {};
+template <> struct AttnCfg<f16x2_t> : AttnCfg<float> {};   // 4-byte elements: the fp32 LDS geometry, byte for byte
 
 __device__ __forceinline__ int swz64(int row) { return (-(row >> 2)) & 3; }
 
@@ -65,10 +66,22 @@ __global__ __launch_bounds__(NWV * 64) void attention_kernel(const T* __restrict
         }
         const int sw = sizeof(T) == 4 ? swz128(key) : swz64(key);
         *(uint4*)(Ks + key * KROW + ((ch ^ sw) << 4)) = kv;
-        union { uint4 u; T e[EPC]; } r;
-        r.u = vv;
+        if constexpr (IsSplit<T>::value) {
+            // V^T rows keep the operand format ALONG THE KEYS: keys 4c .. 4c+3 of head-dim row d are the chunk [4 hi | 4 lo] at 16 c
+            union { uint4 u; f16_t h[8]; } r;
+            r.u = vv;
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) *(T*)(Vt + (ch * EPC + e) * VS + key * (int)sizeof(T)) = r.e[e];
+            for (int e = 0; e < 4; ++e) {
+                char* dst = Vt + (ch * 4 + e) * VS + (key >> 2) * 16 + (key & 3) * 2;
+                *(f16_t*)dst = r.h[e];
+                *(f16_t*)(dst + 8) = r.h[4 + e];
+            }
+        } else {
+            union { uint4 u; T e[EPC]; } r;
+            r.u = vv;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) *(T*)(Vt + (ch * EPC + e) * VS + key * (int)sizeof(T)) = r.e[e];
+        }
     }
     __syncthreads();
 
@@ -98,7 +111,7 @@ __global__ __launch_bounds__(NWV * 64) void attention_kernel(const T* __restrict
                 acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 const char* kr = Ksq + (t * 16 + lr) * KROW;
                 const uint4 kf[2] = {*(const uint4*)(kr + o0), *(const uint4*)(kr + o1)};
-                Mma<float>::run(kf, qf, acc[t]);
+                Mma<T>::run(kf, qf, acc[t]);
             }
         } else {
             uint4 qf = make_uint4(0, 0, 0, 0);
@@ -126,7 +139,9 @@ __global__ __launch_bounds__(NWV * 64) void attention_kernel(const T* __restrict
             for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc[t][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 16));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float nm = -mx * c2;
+        // f16x2: P = exp2(.. + 12), i.e. scaled by 2^12 (at most 4096) so that the lo halves of small probabilities stay normal fp16
+        // numbers; the row sum carries the same factor and cancels it in 1 / sum
+        const float nm = -mx * c2 + (IsSplit<T>::value ? 12.0f : 0.0f);
         float sum = 0.f;
 #pragma unroll
         for (int t = 0; t < MAXT; ++t) {
@@ -141,7 +156,18 @@ __global__ __launch_bounds__(NWV * 64) void attention_kernel(const T* __restrict
         // ---- O^T = V^T P^T
         f32x4 o[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
         f32x4 osum = (f32x4){0.f, 0.f, 0.f, 0.f};  // 16-bit modes: row sums by MFMA against a ones fragment
-        if constexpr (sizeof(T) == 4) {
+        if constexpr (IsSplit<T>::value) {
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t) {
+                const float pv[4] = {acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
+                const uint4 pf = Chunk<T>::pack(pv);                   // keys 16 t + 4 g .. + 3 of query lr: [4 hi | 4 lo]
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const uint4 vf = *(const uint4*)(Vtq + (dt * 16 + lr) * VS + (t * 16 + 4 * g) * 4);   // the same keys of head-dim row 16 dt + lr
+                    Mma<T>::half(vf, pf, o[dt]);
+                }
+            }
+        } else if constexpr (sizeof(T) == 4) {
 #pragma unroll
             for (int t = 0; t < MAXT; ++t) {
 #pragma unroll
@@ -188,7 +214,8 @@ __global__ __launch_bounds__(NWV * 64) void attention_kernel(const T* __restrict
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
                 if constexpr (sizeof(T) == 4) {
-                    *(float4*)(orow + dt * 16) = make_float4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+                    const float ov[4] = {o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv};
+                    store4<T>(orow + dt * 16, ov);
                 } else {
                     union { T e[4]; uint2 u; } pk;
 #pragma unroll
@@ -374,9 +401,7 @@ static int launch_attn16(const void* qkv, void* out, int B, int N, int heads, hi
 }
 template <typename T>
 static int attn16_dt(const void* qkv, void* out, int B, int N, int heads, hipStream_t s) {
-    const int tasks = (N + 31) / 32;
-    if (tasks <= 2) return launch_attn16<T, 2>(qkv, out, B, N, heads, s);
-    if (tasks <= 4) return launch_attn16<T, 4>(qkv, out, B, N, heads, s);
+    // only dispatched above 256 keys (k_attention), i.e. at least nine 32-query tasks per (sequence, head): always the 8-wave build
     return launch_attn16<T, 8>(qkv, out, B, N, heads, s);
 }
 
@@ -434,6 +459,7 @@ int k_attention(int dtype, const void* qkv, void* out, int B, int N, int heads, 
         case OCRVI_F32: return attn_dt<float>(qkv, out, B, N, heads, s);
         case OCRVI_BF16: return streaming && N > 256 ? attn16_dt<bf16_t>(qkv, out, B, N, heads, s) : attn_dt<bf16_t>(qkv, out, B, N, heads, s);
         case OCRVI_F16: return streaming && N > 256 ? attn16_dt<f16_t>(qkv, out, B, N, heads, s) : attn_dt<f16_t>(qkv, out, B, N, heads, s);
+        case OCRVI_F16X2: return attn_dt<f16x2_t>(qkv, out, B, N, heads, s);
     }
     set_error("unknown dtype %d", dtype);
     return OCRVI_EINVAL;

@@ -36,6 +36,15 @@ void set_error(const char* fmt, ...);
 // ---------------------------------------------------------------- element types
 typedef __bf16 bf16_t;
 typedef _Float16 f16_t;
+// "f16x2": an fp32-equivalent element kept as TWO fp16 halves, x = hi + lo with hi = RN16(x), lo = RN16(x - hi) (|x - hi - lo| <= 2^-23 |x|
+// while lo is a normal fp16 number, i.e. |x| >= 2^-3; below that the absolute error is at most 2^-25 -- weights are therefore stored
+// scaled by a power of two per layer, ConvParams::wscale).  4 bytes per element, laid out per 16-byte chunk of 4 consecutive elements as
+// [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3]: every byte-level rule of the fp32 path (16-byte chunk = 4 channels, 128-byte K-step = 32 channels,
+// XOR swizzles, LDS-DMA pieces) holds unchanged, and an MFMA operand register quartet is (hi, lo) of 4 k-slots: with both operands in
+// that form   mfma16x16x32_f16(a, b) = sum hi_a hi_b + lo_a lo_b   and   mfma16x16x32_f16(swap(a), b) = sum lo_a hi_b + hi_a lo_b,
+// i.e. all four partial products of 16 k-steps in two instructions on the 16-bit matrix pipe (8x the fp32 MFMA rate per k-step),
+// accumulated in fp32.  Only ever addressed in whole chunks (Chunk<f16x2_t>) or through load_elem / store_elem.
+struct f16x2_t { uint32_t raw; };
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -44,8 +53,14 @@ template <typename T> struct TypeInfo;
 template <> struct TypeInfo<float> { static constexpr int dtype = OCRVI_F32; static constexpr int EPC = 4; };
 template <> struct TypeInfo<bf16_t> { static constexpr int dtype = OCRVI_BF16; static constexpr int EPC = 8; };
 template <> struct TypeInfo<f16_t> { static constexpr int dtype = OCRVI_F16; static constexpr int EPC = 8; };
+template <> struct TypeInfo<f16x2_t> { static constexpr int dtype = OCRVI_F16X2; static constexpr int EPC = 4; };
+template <typename T> struct IsSplit { static constexpr bool value = false; };
+template <> struct IsSplit<f16x2_t> { static constexpr bool value = true; };
+template <typename T> struct IsF32 { static constexpr bool value = false; };
+template <> struct IsF32<float> { static constexpr bool value = true; };
 
-static inline size_t dtype_size(int dt) { return dt == OCRVI_F32 ? 4 : 2; }
+static inline size_t dtype_size(int dt) { return (dt == OCRVI_F32 || dt == OCRVI_F16X2) ? 4 : 2; }
+static inline bool dtype_valid(int dt) { return dt >= OCRVI_F32 && dt <= OCRVI_F16X2; }
 
 template <typename T> __host__ __device__ inline T from_f32(float v) { return (T)v; }
 template <typename T> __host__ __device__ inline float to_f32(T v) { return (float)v; }
@@ -94,6 +109,66 @@ template <> struct Chunk<f16_t> {
     }
 };
 
+template <> struct Chunk<f16x2_t> {   // [4 hi | 4 lo]
+    static constexpr int N = 4;
+    __device__ static inline void unpack(const uint4& u, float* f) {
+        union { uint4 u; f16_t h[8]; } r;
+        r.u = u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] = (float)r.h[i] + (float)r.h[4 + i];
+    }
+    __device__ static inline uint4 pack(const float* f) {
+        union { f16_t h[8]; uint4 u; } r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            r.h[i] = (f16_t)f[i];
+            r.h[4 + i] = (f16_t)(f[i] - (float)r.h[i]);
+        }
+        return r.u;
+    }
+};
+
+// 4 consecutive T elements (16-byte aligned for fp32 / f16x2, 8-byte for the 16-bit types) <-> float[4]
+template <typename T> __device__ __forceinline__ void load4(const T* p, float* f) {
+    if constexpr (IsSplit<T>::value) {
+        Chunk<T>::unpack(*(const uint4*)p, f);
+    } else if constexpr (sizeof(T) == 4) {
+        const float4 v = *(const float4*)p;
+        f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+    } else {
+        union { uint2 u; T h[4]; } r;
+        r.u = *(const uint2*)p;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] = (float)r.h[i];
+    }
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, const float* f) {
+    if constexpr (IsSplit<T>::value) {
+        *(uint4*)p = Chunk<T>::pack(f);
+    } else if constexpr (sizeof(T) == 4) {
+        *(float4*)p = make_float4(f[0], f[1], f[2], f[3]);
+    } else {
+        union { uint2 u; T h[4]; } r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r.h[i] = (T)f[i];
+        *(uint2*)p = r.u;
+    }
+}
+
+// One element by index (test taps, the three-key FRM kernel): plain types index the array, f16x2 picks its two halves out of the chunk.
+template <typename T> __device__ __forceinline__ float load_elem(const T* p, size_t i) { return to_f32<T>(p[i]); }
+template <> __device__ __forceinline__ float load_elem<f16x2_t>(const f16x2_t* p, size_t i) {
+    const f16_t* h = (const f16_t*)(p + (i & ~(size_t)3));
+    return (float)h[i & 3] + (float)h[4 + (i & 3)];
+}
+template <typename T> __device__ __forceinline__ void store_elem(T* p, size_t i, float v) { p[i] = from_f32<T>(v); }
+template <> __device__ __forceinline__ void store_elem<f16x2_t>(f16x2_t* p, size_t i, float v) {
+    f16_t* h = (f16_t*)(p + (i & ~(size_t)3));
+    const f16_t hi = (f16_t)v;
+    h[i & 3] = hi;
+    h[4 + (i & 3)] = (f16_t)(v - (float)hi);
+}
+
 // ---------------------------------------------------------------- MFMA wrappers (16x16 output tile)
 // A fragment is the 32 bytes lane (r = lane&15, g = lane>>4) reads from row r of a [rows][128 B] LDS tile
 // at byte offset 32*g.  The K order inside a 128-byte K-step is therefore permuted identically for both
@@ -132,6 +207,18 @@ template <> struct Mma<f16_t> {
 #pragma unroll
         for (int s = 0; s < 2; ++s)
             c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[s]), __builtin_bit_cast(f16x8, b[s]), c, 0, 0, 0);
+    }
+};
+
+template <> struct Mma<f16x2_t> {   // operands are chunks [4 hi | 4 lo]: hh + ll, then lh + hl with the halves of `a` exchanged
+    __device__ static inline void half(const uint4& a, const uint4& b, f32x4& c) {
+        const uint4 as = make_uint4(a.z, a.w, a.x, a.y);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, as), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+    __device__ static inline void run(const uint4 (&a)[2], const uint4 (&b)[2], f32x4& c) {
+        half(a[0], b[0], c);
+        half(a[1], b[1], c);
     }
 };
 
@@ -212,7 +299,7 @@ struct ProfScope {
     ProfScope(const char* tag, double flops, double bytes, hipStream_t s);
     ~ProfScope();
 };
-static inline const char* dtype_name(int dt) { return dt == OCRVI_F32 ? "f32" : (dt == OCRVI_BF16 ? "bf16" : "f16"); }
+static inline const char* dtype_name(int dt) { return dt == OCRVI_F32 ? "f32" : (dt == OCRVI_BF16 ? "bf16" : (dt == OCRVI_F16 ? "f16" : "f16x2")); }
 
 // ---------------------------------------------------------------- per-device launch state
 // CU count of the CURRENT device (cached per device id) and a once-per-(kernel, device) opt-in to > 64 KiB of dynamic LDS.
@@ -230,6 +317,7 @@ struct DeviceGuard {
 };
 
 // Host fp32 -> T conversion into a byte buffer.
-void convert_to_dtype(const float* src, size_t n, int dtype, void* dst);
+// (f16x2: src is multiplied by `scale` first and n must be a multiple of 4)
+void convert_to_dtype(const float* src, size_t n, int dtype, void* dst, float scale = 1.f);
 
 }  // namespace ocrvi

@@ -1,0 +1,5 @@
+// conv_gemm instantiation for f16x2_t (one TU per dtype: parallel compile).
+#include "conv_launch.h"
+namespace ocrvi {
+template int launch_conv<f16x2_t>(const ConvParams&, int, hipStream_t);
+}

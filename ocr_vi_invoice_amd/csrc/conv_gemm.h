@@ -53,7 +53,14 @@ struct ConvParams {
     int epi_lds = 0;       // stage the output tile through LDS and store whole rows (ST_NHWC only; set by launch_conv)
     int res_in_store = 0;  // fp32 out + fp32 residual, no activation: add the residual in the coalesced store phase
     int patch_lw = 7;      // dcn_pipe: a tile is a (128 >> patch_lw) x (1 << patch_lw) patch of output pixels
+    float wscale = 1.f;    // f16x2: the weights are stored multiplied by 2^s (one power of two per layer, chosen by the packer so that their
+                           // lo halves are normal fp16 numbers); every epilogue multiplies the accumulator by wscale = 2^-s (exact)
 };
+
+// accumulator -> pre-bias value: the f16x2 weight scale (a no-op for the other types)
+template <typename T> __device__ __forceinline__ float unscale(float acc, float wscale) {
+    if constexpr (IsSplit<T>::value) return acc * wscale; else return acc;
+}
 
 __device__ __forceinline__ int fastdiv(int n, unsigned long long mg) { return (int)(((unsigned long long)(unsigned)n * mg) >> 40); }
 
@@ -271,7 +278,8 @@ __global__ __launch_bounds__(256, (ConvOcc<AMODE, BM, BN>::value)) void conv_gem
                         for (int a = 0; a < NI; ++a) {
                             const int nl = wn * TN + a * 16 + 4 * g;  // column inside the tile
                             const int n = en0 + nl;
-                            float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
+                            float v[4] = {unscale<T>(acc[a][b][0], p.wscale), unscale<T>(acc[a][b][1], p.wscale), unscale<T>(acc[a][b][2], p.wscale),
+                                          unscale<T>(acc[a][b][3], p.wscale)};
                             const int nglob = grp * p.N_g + (n < p.N_g ? n : 0);
                             if (p.bias) {
                                 const float4 bv = *(const float4*)(p.bias + nglob);
@@ -284,17 +292,19 @@ __global__ __launch_bounds__(256, (ConvOcc<AMODE, BM, BN>::value)) void conv_gem
                                     const float4 rv = *(const float4*)((const float*)p.res + ro);
                                     v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
                                 } else {
-                                    const T* rp = (const T*)p.res + ro;
+                                    float rv[4];
+                                    load4<T>((const T*)p.res + ro, rv);
 #pragma unroll
-                                    for (int r = 0; r < 4; ++r) v[r] += to_f32<T>(rp[r]);
+                                    for (int r = 0; r < 4; ++r) v[r] += rv[r];
                                 }
                             }
                             if (!p.res_post) activate(v);
                             const int byte = nl * osz;
                             char* dst = smem + rl * row_bytes + ((((byte >> 4) ^ rl) & (cpr - 1)) << 4) + (byte & 15);
                             if (osz == 4) {
-                                *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
-                            } else {
+                                if (IsSplit<T>::value && !p.out_f32) *(uint4*)dst = Chunk<T>::pack(v);
+                                else *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+                            } else if constexpr (sizeof(T) == 2) {
                                 union { T h[4]; uint2 u; } pk;
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) pk.h[r] = from_f32<T>(v[r]);
@@ -340,7 +350,7 @@ __global__ __launch_bounds__(256, (ConvOcc<AMODE, BM, BN>::value)) void conv_gem
                         const int co = n & 63;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const float v = fmaxf(acc[a][b][r] + p.bias[grp * p.N_g + n + r], 0.f);   // deconv1 + BN + ReLU
+                            const float v = fmaxf(unscale<T>(acc[a][b][r], p.wscale) + p.bias[grp * p.N_g + n + r], 0.f);   // deconv1 + BN + ReLU
                             const float4 wv = *(const float4*)(w2 + (co + r) * 4);
                             q[0] = fmaf(v, wv.x, q[0]); q[1] = fmaf(v, wv.y, q[1]); q[2] = fmaf(v, wv.z, q[2]); q[3] = fmaf(v, wv.w, q[3]);
                         }
@@ -375,7 +385,8 @@ __global__ __launch_bounds__(256, (ConvOcc<AMODE, BM, BN>::value)) void conv_gem
             for (int a = 0; a < NI; ++a) {
                 const int n = en0 + wn * TN + a * 16 + 4 * g;  // within group
                 if (n >= p.N_g) continue;
-                float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
+                float v[4] = {unscale<T>(acc[a][b][0], p.wscale), unscale<T>(acc[a][b][1], p.wscale), unscale<T>(acc[a][b][2], p.wscale),
+                              unscale<T>(acc[a][b][3], p.wscale)};
                 const int nglob = grp * p.N_g + n;
                 if (p.store_mode == ST_DCN_OFFS) {
                     float* o = (float*)p.out + orow * 32 + n;
@@ -399,9 +410,10 @@ __global__ __launch_bounds__(256, (ConvOcc<AMODE, BM, BN>::value)) void conv_gem
                         const float4 rv = *(const float4*)((const float*)p.res + ro);
                         v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
                     } else {
-                        const T* rp = (const T*)p.res + ro;
+                        float rv[4];
+                        load4<T>((const T*)p.res + ro, rv);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += to_f32<T>(rp[r]);
+                        for (int r = 0; r < 4; ++r) v[r] += rv[r];
                     }
                 }
                 if (!p.res_post) activate(v);
@@ -412,14 +424,8 @@ __global__ __launch_bounds__(256, (ConvOcc<AMODE, BM, BN>::value)) void conv_gem
                 } else {
                     oo = orow * p.ldo + p.out_coff + nglob;
                 }
-                if (p.out_f32 || sizeof(T) == 4) {
-                    *(float4*)((float*)p.out + oo) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-                    union { T h[4]; uint2 u; } pk;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) pk.h[r] = from_f32<T>(v[r]);
-                    *(uint2*)((T*)p.out + oo) = pk.u;
-                }
+                if (p.out_f32 || IsF32<T>::value) *(float4*)((float*)p.out + oo) = make_float4(v[0], v[1], v[2], v[3]);
+                else store4<T>((T*)p.out + oo, v);
             }
         }
     };
@@ -490,16 +496,17 @@ static inline int conv_bn_for(int n_g) {
     const int bn = n_g > 64 ? 128 : (n_g > 32 ? 64 : 32);
     return bn > cap ? cap : bn;
 }
-static inline int conv_bke(int dtype) { return dtype == OCRVI_F32 ? 32 : 64; }
+static inline int conv_bke(int dtype) { return dtype_size(dtype) == 4 ? 32 : 64; }   // elements per 128-byte K-step
 
 // Deformable layers with whole 128-byte channel blocks (64 channels in 16 bits, 32 in fp32) run on dcn_pipe.h, whose K order is
 // (channel block, tap, channel) instead of (tap, channel): packer and launcher must agree, so both ask this.
-static inline int dcn_pipe_block(int dtype) { return dtype == OCRVI_F32 ? 32 : 64; }
+static inline int dcn_pipe_block(int dtype) { return dtype_size(dtype) == 4 ? 32 : 64; }
 static inline bool dcn_pipe_packing(int dtype, int cin_g) {
     static const bool on = !(getenv("OCRVI_DCN_PIPE") && atoi(getenv("OCRVI_DCN_PIPE")) == 0);   // A/B switch
     // fp32: measured equal to conv_gemm's AM_DCN mode (both sit at ~56 % of the fp32 MFMA peak: with fp32 MFMAs 16x slower the gather is
     // hidden either way and what is left is tile-count quantisation: 600 tiles of 128 pixels on 256 CUs), so fp32 stays on conv_gemm
     static const bool on32 = getenv("OCRVI_DCN_PIPE_F32") && atoi(getenv("OCRVI_DCN_PIPE_F32")) != 0;
+    // (f16x2: MFMAs are 4x shorter than fp32's per K-step, so the gather is no longer hidden behind them: pipelined, like the 16-bit types)
     return on && (dtype != OCRVI_F32 || on32) && cin_g % dcn_pipe_block(dtype) == 0;
 }
 
@@ -511,10 +518,11 @@ struct PackedConv {
     std::vector<char> bytes;
     std::vector<float> bias;  // expanded (ST_SHUFFLE2: 4x)
     int Np = 0, Kp = 0, N_g = 0, Cin_g = 0, groups = 1, KH = 1;
+    float wscale = 1.f;       // f16x2: what the epilogue multiplies the accumulator by (the stored weights are w / wscale)
 };
 // w: [Cout][Cin_g][KH][KW] fp32 (conv) -- amode AM_CONV1/AM_CONV3/AM_DCN/AM_ROWS
 PackedConv pack_conv(const float* w, const float* bias, int cout, int cin_g, int kh, int kw, int groups, int amode, int dtype);
-// ConvTranspose2d(k=2,s=2) weight [Cin][Cout][2][2] -> GEMM [n=(a*2+b)*Cout+co][k=ci]
-PackedConv pack_deconv2(const float* w, const float* bias, int cin, int cout, int dtype);
+// `groups` ConvTranspose2d(k=2,s=2) weights [Cin][Cout][2][2] -> grouped GEMM [group][n=(a*2+b)*Cout+co][k=ci]
+PackedConv pack_deconv2(const float* const* w, const float* const* bias, int groups, int cin, int cout, int dtype);
 
 }  // namespace ocrvi

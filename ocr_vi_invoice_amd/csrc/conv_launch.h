@@ -124,7 +124,11 @@ static int launch_mode(const ConvParams& p, hipStream_t stream) {
         if (p.Np % 256 == 0) {
             int n_cu = 0;
             OCRVI_TRY(device_cus(&n_cu));
-            if (cdiv(p.M, 64) * (p.Np / 256) < 3 * n_cu) return launch_tile<T, AMODE, 32, 256, 1, 4>(p, stream);
+            bool small = cdiv(p.M, 64) * (p.Np / 256) < 3 * n_cu;
+            const char* fe = getenv("OCRVI_DCN_TILE_M");   // test knob (read per launch so that a test can sweep it): 32 or 64 rows
+            const int force = fe ? atoi(fe) : 0;
+            if (force == 32 || force == 64) small = force == 32;
+            if (small) return launch_tile<T, AMODE, 32, 256, 1, 4>(p, stream);
             return launch_tile<T, AMODE, 64, 256, 2, 2>(p, stream);
         }
         return launch_tile<T, AMODE, 64, 128, 2, 2>(p, stream);
@@ -153,7 +157,9 @@ int launch_conv(const ConvParams& p_in, int amode, hipStream_t stream) {
         const int osz = (p.out_f32 || sizeof(T) == 4) ? 4 : 2, per = 16 / osz;
         p.epi_lds = (!direct && p.store_mode == ST_NHWC && p.res_mode != RES_UP2 && p.N_g % per == 0 && p.ldo % per == 0 &&
                      p.out_coff % per == 0 && ((uintptr_t)p.out & 15) == 0) ? 1 : 0;
-        p.res_in_store = (p.epi_lds && p.res_mode == RES_SAME && osz == 4 && (p.res_f32 || sizeof(T) == 4) && p.act == ACT_NONE &&
+        // (raw fp32 on both sides: an fp32 model, or fp32 output AND fp32 residual of a 16-bit / f16x2 one)
+        const bool raw32 = IsF32<T>::value || (p.out_f32 && p.res_f32);
+        p.res_in_store = (p.epi_lds && p.res_mode == RES_SAME && osz == 4 && raw32 && p.act == ACT_NONE &&
                           p.ldr % 4 == 0 && ((uintptr_t)p.res & 15) == 0) ? 1 : 0;
     }
     OCRVI_CHECK(p.x && p.w && p.out, OCRVI_EINVAL, "conv: null operand");

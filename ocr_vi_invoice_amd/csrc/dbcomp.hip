@@ -197,7 +197,8 @@ extern "C" int ocrvi_db_components(int device, const float* prob, int n_pages, i
                 "db_components: bad argument");
     OCRVI_CHECK(W % 32 == 0 && (size_t)H * W < ((size_t)1 << 30), OCRVI_EINVAL, "db_components: W=%d must be a multiple of 32 (and H*W < 2^30)", W);
     OCRVI_CHECK((packed == nullptr) == (offsets == nullptr) && (!packed || pack_cap > 0), OCRVI_EINVAL, "db_components: packed and offsets go together");
-    OCRVI_HIP(hipSetDevice(device));
+    DeviceGuard dg(device);  // launches go to `device`; the caller's current device is restored on return
+    OCRVI_HIP(dg.err);
     hipStream_t s = (hipStream_t)stream;
     int* labels = (int*)workspace;
     const dim3 grid((W + 255) / 256, H, n_pages), block(256);

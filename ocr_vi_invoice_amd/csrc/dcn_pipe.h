@@ -233,7 +233,8 @@ __global__ __launch_bounds__(512, 2) void dcn_pipe_kernel(const ConvParams p) {
                 for (int a = 0; a < NI; ++a) {
                     const int n = n0 + wn * (BN / 2) + 16 * a + 4 * g;
                     if (m >= 0 && n < p.N_g) {
-                        float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
+                        float v[4] = {unscale<T>(acc[a][b][0], p.wscale), unscale<T>(acc[a][b][1], p.wscale), unscale<T>(acc[a][b][2], p.wscale),
+                                      unscale<T>(acc[a][b][3], p.wscale)};
                         if (p.bias) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) v[r] += p.bias[n + r];

@@ -34,8 +34,9 @@ struct ocrvi_det {
 
 extern "C" int ocrvi_det_create(int device, const void* blob_p, size_t blob_bytes, const ocrvi_det_cfg* cfg, ocrvi_det** out) {
     OCRVI_CHECK(cfg && out, OCRVI_EINVAL, "det_create: null argument");
-    OCRVI_CHECK(cfg->dtype >= OCRVI_F32 && cfg->dtype <= OCRVI_F16, OCRVI_EINVAL, "det_create: bad dtype %d", cfg->dtype);
-    OCRVI_HIP(hipSetDevice(device));
+    OCRVI_CHECK(dtype_valid(cfg->dtype), OCRVI_EINVAL, "det_create: bad dtype %d", cfg->dtype);
+    DeviceGuard dg(device);  // the caller's current device is restored on return
+    OCRVI_HIP(dg.err);
     Blob blob;
     OCRVI_TRY(blob.parse(blob_p, blob_bytes));
     std::unique_ptr<ocrvi_det> h(new ocrvi_det);
@@ -76,25 +77,21 @@ extern "C" int ocrvi_det_create(int device, const void* blob_p, size_t blob_byte
     }
     OCRVI_TRY(load_conv(st, blob, "head.conv", 128, 256, 3, 1, AM_CONV3, dt, true, &h->head_conv));
     {   // two ConvTranspose2d(64,64,2,2)+BN+ReLU as ONE grouped pixel-shuffle GEMM (group 0 = binarise, 1 = threshold branch)
-        PackedConv both;
         std::vector<float> w2(2 * 64 * 4), b2(2);
         const char* names[2] = {"head.bin", "head.thr"};
+        const float *dw[2] = {nullptr, nullptr}, *db[2] = {nullptr, nullptr};
         for (int br = 0; br < 2; ++br) {
             const BlobTensor *w = nullptr, *b = nullptr, *ww = nullptr, *bb = nullptr;
             OCRVI_TRY(blob.get(std::string(names[br]) + ".dc1.w", 64, 64, 2, 2, &w));
             OCRVI_TRY(blob.get(std::string(names[br]) + ".dc1.b", 64, 0, 0, 0, &b));
-            PackedConv pc = pack_deconv2(w->data, b->data, 64, 64, dt);
-            if (br == 0) both = pc;
-            else {
-                both.bytes.insert(both.bytes.end(), pc.bytes.begin(), pc.bytes.end());
-                both.bias.insert(both.bias.end(), pc.bias.begin(), pc.bias.end());
-                both.groups = 2;
-            }
+            dw[br] = w->data;
+            db[br] = b->data;
             OCRVI_TRY(blob.get(std::string(names[br]) + ".dc2.w", 64, 1, 2, 2, &ww));
             OCRVI_TRY(blob.get(std::string(names[br]) + ".dc2.b", 1, 0, 0, 0, &bb));
             std::copy(ww->data, ww->data + 256, w2.begin() + br * 256);
             b2[br] = bb->data[0];
         }
+        PackedConv both = pack_deconv2(dw, db, 2, 64, 64, dt);
         OCRVI_TRY(upload_packed(st, both, AM_CONV1, &h->head_dc1));
         h->head_dc1.shuffle_co = 64;
         w2.insert(w2.end(), b2.begin(), b2.end());
@@ -110,7 +107,7 @@ extern "C" int ocrvi_det_create(int device, const void* blob_p, size_t blob_byte
 
 extern "C" void ocrvi_det_destroy(ocrvi_det* h) {
     if (!h) return;
-    (void)hipSetDevice(h->device);
+    DeviceGuard dg(h->device);
     delete h;
 }
 

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams 
                 const int t = fastdiv(mm, p.mg_ow), ow = mm - t * p.OW, img = fastdiv(t, p.mg_oh), oh = t - img * p.OH;
                 rrow = ((size_t)img * (p.OH >> 1) + (oh >> 1)) * (p.OW >> 1) + (ow >> 1);
             }
-            if (f32o) {
+            if constexpr (F32O) {
 #pragma unroll
                 for (int a = 0; a < NI; ++a) {
                     const int n = nb + ch_of(a);
@@ -302,7 +302,8 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams 
         // does not interleave all of a group's GELU polynomials (that costs more registers than the kernel has)
         auto frag = [&](float (&v)[4], const f32x4& c, int a) {
             const float4 bv = *(const float4*)(bias_s + wn * TN + ch_of(a));
-            v[0] = c[0] + bv.x; v[1] = c[1] + bv.y; v[2] = c[2] + bv.z; v[3] = c[3] + bv.w;
+            v[0] = unscale<T>(c[0], p.wscale) + bv.x; v[1] = unscale<T>(c[1], p.wscale) + bv.y;
+            v[2] = unscale<T>(c[2], p.wscale) + bv.z; v[3] = unscale<T>(c[3], p.wscale) + bv.w;
             if (p.res_post) activate(v);
         };
 #pragma unroll
@@ -310,20 +311,27 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams 
             constexpr int q0 = decltype(GRP)::value * SPS;
             const int m = pmt * BM + wm * TM + (q0 + j) * 16 + lr;
             const size_t row_off = (size_t)m * p.ldo + p.out_coff + nb;
-            if (f32o) {
+            if constexpr (F32O) {
 #pragma unroll
                 for (int a = 0; a < NI; ++a) {
                     float v[4];
                     frag(v, pnd[a][q0 + j], a);
                     if (has_res) {
                         const u32x4 u = res_r[j][a];
-                        v[0] += __uint_as_float(u.x); v[1] += __uint_as_float(u.y);
-                        v[2] += __uint_as_float(u.z); v[3] += __uint_as_float(u.w);
+                        if (IsSplit<T>::value && !p.res_f32) {   // a residual in the operand format: [4 hi | 4 lo]
+                            float rv[4];
+                            Chunk<T>::unpack(make_uint4(u.x, u.y, u.z, u.w), rv);
+                            v[0] += rv[0]; v[1] += rv[1]; v[2] += rv[2]; v[3] += rv[3];
+                        } else {
+                            v[0] += __uint_as_float(u.x); v[1] += __uint_as_float(u.y);
+                            v[2] += __uint_as_float(u.z); v[3] += __uint_as_float(u.w);
+                        }
                     }
                     if (!p.res_post) activate(v);
                     const int c = ch_of(a);
                     float* o = (m < p.M && nb + c < p.N_g) ? (float*)p.out + row_off + c : (float*)p.dump_page + lane * 4;
-                    *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+                    if (IsSplit<T>::value && !p.out_f32) *(uint4*)o = Chunk<T>::pack(v);
+                    else *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else {

@@ -3,6 +3,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <math.h>
+
+#include <algorithm>
 #include <map>
 #include <mutex>
 
@@ -83,9 +86,18 @@ static inline uint16_t f32_to_bf16_bits(float f) {
     u += 0x7fffu + ((u >> 16) & 1);
     return (uint16_t)(u >> 16);
 }
-void convert_to_dtype(const float* src, size_t n, int dtype, void* dst) {
+void convert_to_dtype(const float* src, size_t n, int dtype, void* dst, float scale) {
     if (dtype == OCRVI_F32) {
         memcpy(dst, src, n * 4);
+    } else if (dtype == OCRVI_F16X2) {   // chunks of 4 elements: [4 hi | 4 lo], x * scale = hi + lo (n % 4 == 0: rows are padded to 32)
+        _Float16* d = (_Float16*)dst;
+        for (size_t i = 0; i < n; ++i) {
+            const float x = src[i] * scale;
+            const _Float16 hi = (_Float16)x;
+            const size_t c = i >> 2, j = i & 3;
+            d[8 * c + j] = hi;
+            d[8 * c + 4 + j] = (_Float16)(x - (float)hi);
+        }
     } else if (dtype == OCRVI_BF16) {
         uint16_t* d = (uint16_t*)dst;
         for (size_t i = 0; i < n; ++i) d[i] = f32_to_bf16_bits(src[i]);
@@ -99,7 +111,21 @@ void convert_to_dtype(const float* src, size_t n, int dtype, void* dst) {
 static PackedConv finish_pack(const std::vector<float>& wt, int groups, int Np, int Kp, int dtype) {
     PackedConv pc;
     pc.bytes.resize(wt.size() * dtype_size(dtype));
-    convert_to_dtype(wt.data(), wt.size(), dtype, pc.bytes.data());
+    float scale = 1.f;
+    if (dtype == OCRVI_F16X2) {
+        // one power of two per layer that puts the largest |w| into [2^13, 2^14): far from fp16's 65504, and every weight within 2^-17
+        // of the largest keeps a NORMAL lo half (full 2^-23 relative accuracy; smaller ones are off by at most 2^-39 of the largest).
+        // The kernels' epilogues multiply the accumulator by the inverse, which is exact.
+        float mx = 0.f;
+        for (float v : wt) mx = std::max(mx, fabsf(v));
+        if (mx > 0.f && std::isfinite(mx)) {
+            int e = 0;
+            (void)frexpf(mx, &e);                       // mx in [2^(e-1), 2^e)
+            scale = ldexpf(1.0f, std::min(std::max(14 - e, -100), 100));
+        }
+        pc.wscale = 1.0f / scale;
+    }
+    convert_to_dtype(wt.data(), wt.size(), dtype, pc.bytes.data(), scale);
     pc.Np = Np;
     pc.Kp = Kp;
     pc.groups = groups;
@@ -139,21 +165,23 @@ PackedConv pack_conv(const float* w, const float* bias, int cout, int cin_g, int
     return pc;
 }
 
-PackedConv pack_deconv2(const float* w, const float* bias, int cin, int cout, int dtype) {
+PackedConv pack_deconv2(const float* const* w, const float* const* bias, int groups, int cin, int cout, int dtype) {
     const int bke = conv_bke(dtype);
     const int n_g = 4 * cout;
     const int bn = conv_bn_for(n_g);
     const int Np = cdiv(n_g, bn) * bn, Kp = cdiv(cin, bke) * bke;
-    std::vector<float> wt((size_t)Np * Kp, 0.f);
-    for (int ci = 0; ci < cin; ++ci)
-        for (int co = 0; co < cout; ++co)
-            for (int ab = 0; ab < 4; ++ab) wt[(size_t)(ab * cout + co) * Kp + ci] = w[((size_t)ci * cout + co) * 4 + ab];
-    PackedConv pc = finish_pack(wt, 1, Np, Kp, dtype);
+    std::vector<float> wt((size_t)groups * Np * Kp, 0.f);
+    for (int g = 0; g < groups; ++g)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int co = 0; co < cout; ++co)
+                for (int ab = 0; ab < 4; ++ab) wt[((size_t)g * Np + ab * cout + co) * Kp + ci] = w[g][((size_t)ci * cout + co) * 4 + ab];
+    PackedConv pc = finish_pack(wt, groups, Np, Kp, dtype);   // (one f16x2 weight scale for all groups: they share a launch)
     pc.N_g = n_g;
     pc.Cin_g = cin;
-    pc.bias.resize(n_g);
-    for (int ab = 0; ab < 4; ++ab)
-        for (int co = 0; co < cout; ++co) pc.bias[ab * cout + co] = bias ? bias[co] : 0.f;
+    pc.bias.resize((size_t)groups * n_g);
+    for (int g = 0; g < groups; ++g)
+        for (int ab = 0; ab < 4; ++ab)
+            for (int co = 0; co < cout; ++co) pc.bias[(size_t)g * n_g + ab * cout + co] = (bias && bias[g]) ? bias[g][co] : 0.f;
     return pc;
 }
 
@@ -310,6 +338,7 @@ int launch_conv_dt(int dtype, const ConvParams& p, int amode, hipStream_t stream
         case OCRVI_F32: return launch_conv<float>(p, amode, stream);
         case OCRVI_BF16: return launch_conv<bf16_t>(p, amode, stream);
         case OCRVI_F16: return launch_conv<f16_t>(p, amode, stream);
+        case OCRVI_F16X2: return launch_conv<f16x2_t>(p, amode, stream);
     }
     set_error("unknown dtype %d", dtype);
     return OCRVI_EINVAL;

@@ -9,6 +9,7 @@ namespace ocrvi {
         case OCRVI_F32: { using T = float; CALL; break; }            \
         case OCRVI_BF16: { using T = bf16_t; CALL; break; }          \
         case OCRVI_F16: { using T = f16_t; CALL; break; }            \
+        case OCRVI_F16X2: { using T = f16x2_t; CALL; break; }        \
         default: set_error("unknown dtype %d", dt); return OCRVI_EINVAL; \
     }
 
@@ -21,29 +22,6 @@ __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
     return v;
-}
-
-// 4 consecutive T elements <-> float[4]
-template <typename T> __device__ __forceinline__ void load4(const T* p, float* f) {
-    if constexpr (sizeof(T) == 4) {
-        const float4 v = *(const float4*)p;
-        f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
-    } else {
-        union { uint2 u; T h[4]; } r;
-        r.u = *(const uint2*)p;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) f[i] = (float)r.h[i];
-    }
-}
-template <typename T> __device__ __forceinline__ void store4(T* p, const float* f) {
-    if constexpr (sizeof(T) == 4) {
-        *(float4*)p = make_float4(f[0], f[1], f[2], f[3]);
-    } else {
-        union { uint2 u; T h[4]; } r;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) r.h[i] = (T)f[i];
-        *(uint2*)p = r.u;
-    }
 }
 
 // ------------------------------------------------------------------ NCHW3 f32 -> padded NHWC4 T
@@ -109,7 +87,7 @@ int k_maxpool3x3s2(int dtype, const void* x, void* y, int N, int H, int W, int C
     OCRVI_CHECK(x && y && C % 8 == 0 && H >= 2 && W >= 2, OCRVI_EINVAL, "maxpool: bad shape C=%d", C);
     ProfScope ps_("maxpool3x3s2", 0.0, (double)N*H*W*C*dtype_size(dtype)*1.25, s);
     const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
-    const size_t total = (size_t)N * OH * OW * (C / (dtype == OCRVI_F32 ? 4 : 8));
+    const size_t total = (size_t)N * OH * OW * (C / (dtype_size(dtype) == 4 ? 4 : 8));
     const int grid = (int)std::min<size_t>((total + 255) / 256, 16384);
     DISPATCH_DT(dtype, hipLaunchKernelGGL(maxpool3x3s2_kernel<T>, dim3(grid), dim3(256), 0, s, (const T*)x, (T*)y, N, H, W, C, OH, OW));
     OCRVI_HIP(hipGetLastError());
@@ -234,7 +212,7 @@ __global__ void nhwc_to_nchw_f32_kernel(const T* __restrict__ x, float* __restri
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: ty 0..7
     for (int r = ty; r < 32; r += 8) {
         const int p = p0 + r, c = c0 + tx;
-        tile[r][tx] = (p < HW && c < C) ? to_f32<T>(x[((size_t)n * HW + p) * ld + coff + c]) : 0.f;
+        tile[r][tx] = (p < HW && c < C) ? load_elem<T>(x, ((size_t)n * HW + p) * ld + coff + c) : 0.f;
     }
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
@@ -270,8 +248,8 @@ __global__ void frm_vertical_kernel(const T* __restrict__ kv, const float* __res
     for (int h = 0; h < 8; ++h) {
         if (h >= H) break;
         const size_t tok = ((size_t)b * H + h) * W + w;
-        const float kk = to_f32<T>(kv[tok * 2 * D + hd * 32 + d]);
-        vv[h] = to_f32<T>(kv[tok * 2 * D + D + hd * 32 + d]);
+        const float kk = load_elem<T>(kv, tok * 2 * D + hd * 32 + d);
+        vv[h] = load_elem<T>(kv, tok * 2 * D + D + hd * 32 + d);
         float s = q * kk;
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o);
@@ -286,7 +264,7 @@ __global__ void frm_vertical_kernel(const T* __restrict__ kv, const float* __res
         den += p;
         acc += p * vv[h];
     }
-    out[col * D + hd * 32 + d] = from_f32<T>(acc / den);
+    store_elem<T>(out, col * D + hd * 32 + d, acc / den);
 }
 int k_frm_vertical(int dtype, const void* kv, const float* vq, void* out, int B, int H, int W, int D, hipStream_t s) {
     OCRVI_CHECK(kv && vq && out && D % 32 == 0 && H >= 1 && H <= 8, OCRVI_EINVAL, "frm vertical: D=%d H=%d unsupported", D, H);

@@ -368,7 +368,7 @@ void pack_mlp_stream(const float* w1, const float* w2, int D, int dtype, std::ve
     convert_to_dtype(buf.data(), buf.size(), dtype, out.data());
 }
 
-bool mlp_fused_eligible(int dtype, int D) { return dtype != OCRVI_F32 && D % 128 == 0 && D >= 128 && D <= 384; }
+bool mlp_fused_eligible(int dtype, int D) { return (dtype == OCRVI_BF16 || dtype == OCRVI_F16) && D % 128 == 0 && D >= 128 && D <= 384; }
 
 template <typename T, int D, int WPS, int R, int TB = 2>
 static int launch_mlp(const MlpParams& p, hipStream_t s) {

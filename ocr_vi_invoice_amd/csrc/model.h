@@ -27,6 +27,7 @@ struct ConvLayer {
     float* bias = nullptr;
     int Np = 0, Kp = 0, N_g = 0, Cin_g = 0, groups = 1, KH = 1, amode = AM_CONV1;
     int shuffle_co = 0;
+    float wscale = 1.f;   // f16x2 weight scale (PackedConv::wscale)
 };
 
 int upload_packed(DeviceStore& st, const PackedConv& pc, int amode, ConvLayer* L);

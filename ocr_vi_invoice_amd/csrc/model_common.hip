@@ -8,6 +8,7 @@ int upload_packed(DeviceStore& st, const PackedConv& pc, int amode, ConvLayer* L
     if (!pc.bias.empty()) OCRVI_TRY(st.upload_f32(pc.bias, &L->bias));
     L->Np = pc.Np; L->Kp = pc.Kp; L->N_g = pc.N_g; L->Cin_g = pc.Cin_g; L->groups = pc.groups; L->KH = pc.KH;
     L->amode = amode;
+    L->wscale = pc.wscale;
     return OCRVI_OK;
 }
 
@@ -41,6 +42,7 @@ int conv(Runner& r, const ConvLayer& L, const Tensor& x, const Tensor& y, const 
     p.Cin_g = L.Cin_g; p.cin_off = o.cin_off;
     p.N_g = L.N_g; p.Np = L.Np; p.Kp = L.Kp; p.groups = L.groups;
     p.store_mode = o.store_mode;
+    p.wscale = L.wscale;
     if (o.store_mode == ST_SHUFFLE2) {
         p.OH = y.h / 2; p.OW = y.w / 2; p.shuffle_co = L.shuffle_co;
     } else if (o.store_mode == ST_DB_TAIL) {  // y is the fp32 logit map [n, 4*OH, 4*OW, 1]

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(512, 1) void offs_conv_kernel(const ConvParams p, i
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr) {
                         const int nn = n + rr;
-                        float tv = nn < p.N_g ? acc[a][b][rr] + p.bias[nn] : 0.f;
+                        float tv = nn < p.N_g ? unscale<T>(acc[a][b][rr], p.wscale) + p.bias[nn] : 0.f;
                         if (nn >= 18) tv = nn < p.N_g ? 1.0f / (1.0f + expf(-tv)) : 0.f;
                         v[rr] = tv;
                     }

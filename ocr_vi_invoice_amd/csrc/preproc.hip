@@ -124,7 +124,8 @@ using namespace ocrvi;
 
 extern "C" int ocrvi_resize_u8(int device, const uint8_t* src, int src_h, int src_w, uint8_t* dst, int dst_h, int dst_w, void* stream) {
     OCRVI_CHECK(src && dst && src_h > 0 && src_w > 0 && dst_h > 0 && dst_w > 0, OCRVI_EINVAL, "resize_u8: bad argument");
-    OCRVI_HIP(hipSetDevice(device));
+    DeviceGuard dg(device);  // the caller's current device is restored on return
+    OCRVI_HIP(dg.err);
     const size_t total = (size_t)dst_h * dst_w;
     const int grid = (int)std::min<size_t>((total + 255) / 256, 16384);
     hipLaunchKernelGGL(resize_u8_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, src_h, src_w, dst, dst_h, dst_w);
@@ -134,7 +135,8 @@ extern "C" int ocrvi_resize_u8(int device, const uint8_t* src, int src_h, int sr
 
 extern "C" int ocrvi_normalize_u8(int device, const uint8_t* images, int N, int H, int W, float* out, void* stream) {
     OCRVI_CHECK(images && out && N > 0 && H > 0 && W > 0, OCRVI_EINVAL, "normalize_u8: bad argument");
-    OCRVI_HIP(hipSetDevice(device));
+    DeviceGuard dg(device);  // the caller's current device is restored on return
+    OCRVI_HIP(dg.err);
     const size_t total = (size_t)N * H * W;
     const int grid = (int)std::min<size_t>((total + 255) / 256, 16384);
     hipLaunchKernelGGL(normalize_u8_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, images, out, N, H, W);
@@ -145,7 +147,8 @@ extern "C" int ocrvi_normalize_u8(int device, const uint8_t* images, int N, int 
 extern "C" int ocrvi_crop_resize_normalize(int device, const uint8_t* images, int n_img, int H, int W, const int32_t* boxes, int B, int out_h,
                                            int out_w, float* out, void* stream) {
     OCRVI_CHECK(images && boxes && out && n_img > 0 && B > 0 && out_h > 0 && out_w > 0, OCRVI_EINVAL, "crop_resize_normalize: bad argument");
-    OCRVI_HIP(hipSetDevice(device));
+    DeviceGuard dg(device);  // the caller's current device is restored on return
+    OCRVI_HIP(dg.err);
     const size_t total = (size_t)B * out_h * out_w;
     const int grid = (int)std::min<size_t>((total + 255) / 256, 16384);
     hipLaunchKernelGGL(crop_resize_normalize_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, images, n_img, H, W, boxes, B, out_h, out_w, out);

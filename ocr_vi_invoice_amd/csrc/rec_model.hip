@@ -71,14 +71,15 @@ static int load_mlp(DeviceStore& st, const Blob& b, const std::string& name, int
 
 extern "C" int ocrvi_rec_create(int device, const void* blob_p, size_t blob_bytes, const ocrvi_rec_cfg* cfg, ocrvi_rec** out) {
     OCRVI_CHECK(cfg && out, OCRVI_EINVAL, "rec_create: null argument");
-    OCRVI_CHECK(cfg->dtype >= OCRVI_F32 && cfg->dtype <= OCRVI_F16, OCRVI_EINVAL, "rec_create: bad dtype %d", cfg->dtype);
+    OCRVI_CHECK(dtype_valid(cfg->dtype), OCRVI_EINVAL, "rec_create: bad dtype %d", cfg->dtype);
     for (int s = 0; s < 3; ++s)
         OCRVI_CHECK(cfg->dims[s] > 0 && cfg->dims[s] % 32 == 0 && cfg->num_blocks[s] > 0 && cfg->num_local[s] >= 0 &&
                         cfg->num_local[s] <= cfg->num_blocks[s],
                     OCRVI_EINVAL, "rec_create: bad stage %d config (dims must be multiples of 32)", s);
     OCRVI_CHECK(cfg->num_classes > 0 && cfg->num_classes % 4 == 0 && cfg->num_classes <= 1024, OCRVI_EINVAL,
                 "rec_create: num_classes=%d must be a multiple of 4 and <= 1024", cfg->num_classes);
-    OCRVI_HIP(hipSetDevice(device));
+    DeviceGuard dg(device);  // the caller's current device is restored on return
+    OCRVI_HIP(dg.err);
     Blob blob;
     OCRVI_TRY(blob.parse(blob_p, blob_bytes));
     std::unique_ptr<ocrvi_rec> h(new ocrvi_rec);
@@ -137,7 +138,7 @@ extern "C" int ocrvi_rec_create(int device, const void* blob_p, size_t blob_byte
 
 extern "C" void ocrvi_rec_destroy(ocrvi_rec* h) {
     if (!h) return;
-    (void)hipSetDevice(h->device);
+    DeviceGuard dg(h->device);
     delete h;
 }
 
@@ -364,7 +365,8 @@ extern "C" int ocrvi_rec_debug_features(ocrvi_rec* h, int B, int H, int W, float
 extern "C" int ocrvi_ctc_greedy(int device, const float* log_probs, int T, int B, int C, int blank_id, int32_t* argmax_ids, int32_t* ids,
                                 int32_t* lens, void* stream) {
     OCRVI_CHECK(log_probs && argmax_ids, OCRVI_EINVAL, "ctc_greedy: log_probs and argmax_ids are required");
-    OCRVI_HIP(hipSetDevice(device));
+    DeviceGuard dg(device);  // the caller's current device is restored on return
+    OCRVI_HIP(dg.err);
     OCRVI_TRY(k_ctc_argmax_tbc(log_probs, argmax_ids, B, T, C, (hipStream_t)stream));
     if (ids || lens) OCRVI_TRY(k_ctc_collapse(argmax_ids, ids, lens, B, T, blank_id, (hipStream_t)stream));
     return OCRVI_OK;

@@ -12,7 +12,7 @@ from . import _lib, weights
 
 class DBNetPP:
     def __init__(self, backbone: str = "resnet50", pretrained: bool = False, in_channels: int = 3, inner_channels: int = 256,
-                 k: float = 50, dcn: bool = True, *, state_dict=None, blob: bytes = None, seed: int = 1234, dtype="bf16",
+                 k: float = 50, dcn: bool = True, *, state_dict=None, blob: bytes = None, seed: int = 1234, dtype="f32",
                  device="cuda:0"):
         if backbone != "resnet50":
             # the reference also offers resnet18 (backbone.py:12-15); the pipeline only uses resnet50 (pipeline2.py:45)
@@ -28,6 +28,7 @@ class DBNetPP:
         self._handle = None
         self._ws = {}
         self.training = False
+        self._seed = seed
         if blob is not None:        # already folded + packed (weights.pack_blob): what rank 0 broadcasts to the other ranks
             self.load_blob(blob)
         else:
@@ -37,12 +38,15 @@ class DBNetPP:
         """nn.Module.load_state_dict semantics for the keys the inference graph uses: with ``strict`` (default) a missing tensor
         raises KeyError-as-RuntimeError like torch does; unexpected keys (the reference's duplicate ``backbone.layerN`` aliases, the
         unused ``fc``, optimizer state in a wrapped checkpoint) are ignored, as the reference's loader effectively does."""
+        if not strict:
+            # nn.Module semantics: tensors the given dict lacks keep their current values (the initial seeded ones on a fresh model)
+            base = dict(self._state) if getattr(self, "_state", None) is not None else weights.make_det_state_dict(self._seed)
+            base.update(weights.unwrap_checkpoint(state_dict))
+            state_dict = base
         try:
             folded = weights.fold_det(state_dict)
         except KeyError as e:
-            if strict:
-                raise RuntimeError(f"Error(s) in loading state_dict for DBNetPP: missing key {e}") from None
-            raise
+            raise RuntimeError(f"Error(s) in loading state_dict for DBNetPP: missing key {e}") from None
         self._state = {k: (v.detach().clone() if isinstance(v, torch.Tensor) else v) for k, v in weights.unwrap_checkpoint(state_dict).items()}
         return self.load_blob(weights.pack_blob(folded))
 
@@ -69,7 +73,9 @@ class DBNetPP:
         dev = torch.device(device)
         if dev.type != "cuda":
             raise ValueError("libocrvi has no CPU path: the product runs on an MI355X (use the reference module for CPU)")
-        if dev != self.device:
+        if dev.index is None:     # model.to('cuda') (the reference's pattern, pipeline2.py:53) = the current device
+            dev = torch.device("cuda", torch.cuda.current_device())
+        if dev != torch.device("cuda", self._dev_index()):
             if getattr(self, "_blob", None) is None:
                 raise RuntimeError("no weights retained to move")
             self.device = dev

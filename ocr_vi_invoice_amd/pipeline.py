@@ -48,12 +48,12 @@ def load_checkpoint(model_path: str):
         return torch.load(model_path, map_location="cpu", weights_only=True)
 
 
-def load_detection_model(model_path: str, device: str = "cuda:0", dtype: str = "bf16") -> DBNetPP:
+def load_detection_model(model_path: str, device: str = "cuda:0", dtype: str = "f32") -> DBNetPP:
     """pipeline2.py:43-67.  The checkpoint is read with ``weights_only=True`` (nothing in the file is executed)."""
     return DBNetPP(pretrained=False, state_dict=load_checkpoint(model_path), device=device, dtype=dtype)
 
 
-def load_recognition_model(model_path: str, device: str = "cuda:0", variant: str = "base", dtype: str = "bf16") -> SVTRv2:
+def load_recognition_model(model_path: str, device: str = "cuda:0", variant: str = "base", dtype: str = "f32") -> SVTRv2:
     """pipeline2.py:72-89."""
     return SVTRv2(variant=variant, in_channels=3, state_dict=load_checkpoint(model_path), device=device, dtype=dtype)
 
@@ -175,7 +175,7 @@ class DBComponents:
         assert W % 32 == 0, "page width must be a multiple of 32"
         self.n, self.H, self.W, self.cap = n_pages, H, W, cap
         self.dev = torch.device(device)
-        self.devi = self.dev.index or 0
+        self.devi = _dev_index(self.dev)   # an index-less 'cuda' means the current device, as in DBNetPP / SVTRv2
         self.pack_cap = int(H * W * pack_frac)
         d = dict(device=self.dev)
         self.bits = torch.empty((n_pages, H, W // 32), dtype=torch.int32, **d)

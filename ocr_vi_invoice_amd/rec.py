@@ -14,7 +14,7 @@ from .vocab import VOCAB, Tokenizer
 
 class SVTRv2:
     def __init__(self, variant: str = "small", in_channels: int = 3, charset=VOCAB, dropout: float = 0.0,
-                 context_window: int = 3, *, state_dict=None, blob: bytes = None, seed: int = 1234, dtype="bf16", device="cuda:0"):
+                 context_window: int = 3, *, state_dict=None, blob: bytes = None, seed: int = 1234, dtype="f32", device="cuda:0"):
         assert variant in weights.REC_VARIANTS, \
             f"Unknown variant: {variant}. Choose from {list(weights.REC_VARIANTS.keys())}"  # svtrv2.py:425
         if in_channels != 3:
@@ -30,6 +30,7 @@ class SVTRv2:
         self._handle = None
         self._ws = {}
         self.training = False
+        self._seed = seed
         if blob is not None:        # already folded + packed (weights.pack_blob): what rank 0 broadcasts to the other ranks
             self.load_blob(blob)
         else:
@@ -39,12 +40,15 @@ class SVTRv2:
     def load_state_dict(self, state_dict, strict: bool = True):
         """nn.Module.load_state_dict semantics for the inference keys: a missing tensor raises RuntimeError when ``strict``; the
         training-only ``sgm.*`` keys (svtrv2.py:252-385) and checkpoint wrappers are ignored."""
+        if not strict:
+            # nn.Module semantics: tensors the given dict lacks keep their current values (the initial seeded ones on a fresh model)
+            base = dict(self._state) if getattr(self, "_state", None) is not None else weights.make_rec_state_dict(self.variant, self._seed)
+            base.update(weights.unwrap_checkpoint(state_dict))
+            state_dict = base
         try:
             folded = weights.fold_rec(state_dict, self.variant)
         except KeyError as e:
-            if strict:
-                raise RuntimeError(f"Error(s) in loading state_dict for SVTRv2: missing key {e}") from None
-            raise
+            raise RuntimeError(f"Error(s) in loading state_dict for SVTRv2: missing key {e}") from None
         self._state = {k: (v.detach().clone() if isinstance(v, torch.Tensor) else v) for k, v in weights.unwrap_checkpoint(state_dict).items()}
         return self.load_blob(weights.pack_blob(folded))
 
@@ -75,7 +79,9 @@ class SVTRv2:
         dev = torch.device(device)
         if dev.type != "cuda":
             raise ValueError("libocrvi has no CPU path: the product runs on an MI355X (use the reference module for CPU)")
-        if dev != self.device:
+        if dev.index is None:     # model.to('cuda') (the reference's pattern, pipeline2.py:53) = the current device
+            dev = torch.device("cuda", torch.cuda.current_device())
+        if dev != torch.device("cuda", self._dev_index()):
             if getattr(self, "_blob", None) is None:
                 raise RuntimeError("no weights retained to move")
             self.device = dev

@@ -11,9 +11,11 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-DT = {"f32": 0, "bf16": 1, "f16": 2}
-# relative-to-output-rms budgets: f32 MFMA is an fmaf chain; bf16 has 8 mantissa bits, fp16 11
-TOL = {"f32": 2e-5, "bf16": 4e-2, "f16": 5e-3}
+DT = {"f32": 0, "bf16": 1, "f16": 2, "f16x2": 3}
+# relative-to-output-rms budgets: f32 MFMA is an fmaf chain; f16x2 (two fp16 halves per operand, all four partial products, fp32
+# accumulation) is held to the SAME budget as fp32; bf16 has 8 mantissa bits, fp16 11
+TOL = {"f32": 2e-5, "f16x2": 2e-5, "bf16": 4e-2, "f16": 5e-3}
+EXACT = ("f32", "f16x2")     # fp32-equivalent modes
 
 
 def _lib():
@@ -60,7 +62,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("dt", ["f32", "f16x2", "bf16", "f16"])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_kernel(case, dt):
     N, Cin, H, W, Co, ks, sh, sw, groups, act = case
@@ -87,7 +89,7 @@ RING_CASES = [
 ]
 
 
-@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("dt", ["f32", "f16x2", "bf16", "f16"])
 @pytest.mark.parametrize("case", RING_CASES)
 def test_ring_gemm_kernel(case, dt):
     N, Cin, H, W, Co, act = case
@@ -114,7 +116,7 @@ RING_CONV3_CASES = [
 ]
 
 
-@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("dt", ["f32", "f16x2", "bf16", "f16"])
 @pytest.mark.parametrize("case", RING_CONV3_CASES)
 def test_ring_conv3x3_kernel(case, dt):
     # (tests/conftest.py lowers the dispatch threshold OCRVI_RING_CONV3_MIN_M from 2^18 rows to 16384 for the whole session)
@@ -150,7 +152,7 @@ GEMM_CASES = [
 ]
 
 
-@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("dt", ["f32", "f16x2", "bf16", "f16"])
 @pytest.mark.parametrize("case", GEMM_CASES)
 def test_ring_gemm_epilogues(case, dt):
     """out = act(a W^T + b (+ res)) or act(a W^T + b) + res through ocrvi_test_gemm against torch fp64->fp32; twice, bit-identical."""
@@ -183,7 +185,7 @@ def test_ring_gemm_epilogues(case, dt):
     assert torch.equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("dt", ["f32", "f16x2", "bf16", "f16"])
 @pytest.mark.parametrize("stride", [1, 2])
 @pytest.mark.parametrize("C_", [128, 256])
 def test_deform_conv_kernel(C_, stride, dt):
@@ -208,6 +210,74 @@ def test_deform_conv_kernel(C_, stride, dt):
     assert _rel_err(out.cpu(), ref) < TOL[dt], _rel_err(out.cpu(), ref)
 
 
+DCN_REAL_CASES = [
+    # the detector's own deformable layers at 960x1280 (dcn.py:41-59 as called from backbone.py:39-53): (N, C, Ho, Wo, stride).
+    # Layer 2: 128 ch, 120x160; layer 3: 256 ch, 60x80; layer 4: 512 ch, 30x40; stride 2 in the first block of each layer.  These maps
+    # select dcn_pipe patches of 8x16 (layers 2, 3) and 16x8 (layer 4) pixels, two 256-column tiles at 512 channels, and -- in fp32 --
+    # both row tiles of conv_gemm's AM_DCN mode (forced below: the launcher picks by M and CU count).
+    (2, 128, 120, 160, 1), (2, 128, 120, 160, 2), (2, 256, 60, 80, 1), (2, 256, 60, 80, 2), (2, 512, 30, 40, 1), (2, 512, 30, 40, 2),
+]
+
+
+def _dcn_case(case, seed):
+    from oracle import dbnet_cpu
+    N, C_, Ho, Wo, stride = case
+    H, W = Ho * stride, Wo * stride
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, C_, H, W, generator=g)
+    off = torch.randn(N, 18, Ho, Wo, generator=g) * 3.0
+    mask = torch.rand(N, 9, Ho, Wo, generator=g)
+    w = torch.randn(C_, C_, 3, 3, generator=g) / np.sqrt(9 * C_)
+    b = torch.randn(C_, generator=g) * 0.1
+    ref = F.relu(dbnet_cpu.deform_conv2d_gather(x, off, mask, w, stride) + b.view(1, -1, 1, 1))
+    return x, off, mask, w, b, ref
+
+
+def _run_dcn(x, off, mask, w, b, stride, dt):
+    L = _lib()
+    N, C_, H, W = x.shape
+    Ho, Wo = off.shape[-2:]
+    out = torch.empty((N, C_, Ho, Wo), device="cuda")
+    wh, bh = np.ascontiguousarray(w.numpy()), np.ascontiguousarray(b.numpy())
+    xd, od, md = x.cuda(), off.cuda(), mask.cuda()
+    ms = C.c_float(0)
+    L.check(L.load().ocrvi_test_deform_conv(0, DT[dt], xd.data_ptr(), od.data_ptr(), md.data_ptr(), wh.ctypes.data, bh.ctypes.data,
+                                            N, C_, H, W, C_, stride, 1, out.data_ptr(), 0, C.byref(ms)))
+    return out.cpu()
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16x2", "bf16", "f16"])
+@pytest.mark.parametrize("case", DCN_REAL_CASES)
+def test_deform_conv_kernel_detector_shapes(case, dt):
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    x, off, mask, w, b, ref = _dcn_case(case, 31 + sum(case))
+    stride = case[4]
+    tiles = ("32", "64") if (dt == "f32" and case[1] % 256 == 0) else (None,)
+    outs = []
+    for tm in tiles:      # fp32 at >= 256 channels: conv_gemm_kernel<float, AM_DCN, 32, 256> AND <.., 64, 256> (the bench runs the latter)
+        if tm:
+            os.environ["OCRVI_DCN_TILE_M"] = tm
+        try:
+            outs.append(_run_dcn(x, off, mask, w, b, stride, dt))
+        finally:
+            os.environ.pop("OCRVI_DCN_TILE_M", None)
+        # K = 9 C: the fp32 budget (max error of two fp32 summation orders relative to the output rms) grows like sqrt(K): 2e-5 is sized for
+        # K ~ 1000 (tools/split_probe.hip measures 1e-5 .. 3.6e-5 for an fp32 chain at K = 4608)
+        tol = TOL[dt] * (max(1.0, (9 * case[1] / 1152.0) ** 0.5) if dt in EXACT else 1.0)
+        assert _rel_err(outs[-1], ref) < tol, (tm, _rel_err(outs[-1], ref))
+    if len(outs) == 2:      # the row tile only regroups pixels: same sums in the same order
+        assert torch.equal(outs[0], outs[1])
+
+
+def test_deform_conv_f32_large_m_takes_the_64_row_tile_by_itself():
+    """M = 52800 rows at 256 channels crosses launch_mode<AM_DCN>'s own limit (cdiv(M, 64) >= 3 x CUs), as layer 3 of a 16-page chunk
+    does in the bench; no knob."""
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    x, off, mask, w, b, ref = _dcn_case((11, 256, 60, 80, 1), 77)
+    out = _run_dcn(x, off, mask, w, b, 1, "f32")
+    assert _rel_err(out, ref) < TOL["f32"], _rel_err(out, ref)
+
+
 def test_deform_conv_zero_offset_identity():
     """dcn.py:28-29 init: offsets 0 and mask 0.5 -> 0.5 * conv2d."""
     L = _lib()
@@ -227,8 +297,10 @@ def test_deform_conv_zero_offset_identity():
     assert _rel_err(out.cpu(), ref) < 2e-5
 
 
-@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
-@pytest.mark.parametrize("B,N,heads", [(2, 480, 8), (3, 240, 12), (4, 80, 12), (2, 100, 2), (1, 512, 1), (2, 16, 3)])
+@pytest.mark.parametrize("dt", ["f32", "f16x2", "bf16", "f16"])
+@pytest.mark.parametrize("B,N,heads", [(2, 480, 8), (3, 240, 12), (4, 80, 12), (2, 100, 2), (1, 512, 1), (2, 16, 3),
+                                       # > 256 keys with N % 32 != 0: the streaming kernel's key masking (a 48x200 crop has 300 tokens)
+                                       (2, 300, 4), (1, 264, 2), (1, 500, 1)])
 def test_attention_kernel(B, N, heads, dt):
     L = _lib()
     lib = L.load()
@@ -290,7 +362,7 @@ def test_mlp_fused_kernel(M, D, mode, dt):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
-@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("dt", ["f32", "f16x2", "bf16", "f16"])
 @pytest.mark.parametrize("case", [
     # (N, C, H, W, stride): ragged maps (partial 16-pixel blocks, fewer rows than a tile, single pixels) and the detector's own shapes
     (2, 128, 9, 11, 1), (1, 256, 20, 35, 1), (3, 128, 5, 40, 2), (1, 512, 1, 1, 1), (2, 256, 17, 33, 2), (1, 128, 30, 40, 1),
@@ -307,7 +379,7 @@ def test_offset_conv_kernel(case, dt):
     w = torch.randn(27, Cc, 3, 3, generator=g) / (9 * Cc) ** 0.5
     b = torch.randn(27, generator=g) * 0.3
     Ho, Wo = (H - 1) // st + 1, (W - 1) // st + 1
-    if dt != "f32":      # the 16-bit kernels see operands rounded to their type; compare against that
+    if dt not in EXACT:      # the 16-bit kernels see operands rounded to their type; compare against that
         td = torch.bfloat16 if dt == "bf16" else torch.float16
         xr, wr = x.to(td).double(), w.to(td).double()
     else:
@@ -328,6 +400,6 @@ def test_offset_conv_kernel(case, dt):
     for o2 in outs[1:]:      # tile heights only regroup pixels: every output element sees the same sums in the same order
         assert torch.equal(outs[0], o2)
     assert torch.isfinite(out).all() and float(out[..., 27:].abs().max()) == 0.0
-    tol = 2e-5 if dt == "f32" else 2e-3      # fp32 accumulation of exactly representable products; the sigmoid compresses further
+    tol = 2e-5 if dt in EXACT else 2e-3      # fp32 accumulation of exactly representable products; the sigmoid compresses further
     err = float((out[..., :27] - ref).abs().max())
     assert err < tol, err

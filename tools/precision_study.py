@@ -54,6 +54,21 @@ def main():
     out["f32"] = {"crops": len(t32), "min_top2_margin": float(margin.min()), "margin_p1": float(margin.flatten().kthvalue(max(1, margin.numel() // 100)).values),
                   "steps_with_margin_lt_0.05": int((margin < 0.05).sum()), "steps": int(margin.numel())}
     am32 = lp32.argmax(-1)
+    ref_lp = ref_txt = None
+
+    def vs_cpu(lp, txt):
+        """one mode against the CPU oracle on the first n crops: strings, argmax decisions, max |dlog-prob|, mean |d(top-2 margin)|"""
+        n = ref_lp.shape[0]
+        bad = [i for i in range(n) if ref_txt[i] != txt[i]]
+        rm = ref_lp.topk(2, -1)
+        rmargin = rm.values[..., 0] - rm.values[..., 1]
+        flips = ref_lp.argmax(-1) != lp[:n].argmax(-1)
+        gm = lp[:n].gather(-1, rm.indices)           # this mode's log-probs at the oracle's top-2 classes
+        return {"crops": n, "strings_differ": len(bad), "steps_argmax_differ": int(flips.sum()),
+                "max_abs_err": float((ref_lp - lp[:n]).abs().max()), "mean_abs_err": float((ref_lp - lp[:n]).abs().mean()),
+                "mean_abs_top2_margin_err": float(((gm[..., 0] - gm[..., 1]) - rmargin).abs().mean()),
+                "largest_ref_margin_at_a_flip": float(rmargin[flips].max()) if flips.any() else 0.0}
+
     if args.cpu_crops:
         from oracle import svtrv2_cpu
         from ocr_vi_invoice_amd.vocab import Tokenizer
@@ -66,13 +81,7 @@ def main():
             ref_lp.append(lp.permute(1, 0, 2))
             ref_txt += Tokenizer().decode(svtrv2_cpu.greedy_ids(lp))
         ref_lp = torch.cat(ref_lp)
-        bad = [i for i in range(n) if ref_txt[i] != t32[i]]
-        rm = ref_lp.topk(2, -1).values
-        rmargin = rm[..., 0] - rm[..., 1]
-        flips = ref_lp.argmax(-1) != am32[:n]
-        out["f32_gpu_vs_cpu_oracle"] = {"crops": n, "strings_differ": len(bad), "steps_argmax_differ": int(flips.sum()),
-                                        "max_abs_err": float((ref_lp - lp32[:n]).abs().max()),
-                                        "largest_ref_margin_at_a_flip": float(rmargin[flips].max()) if flips.any() else 0.0}
+        out["f32_gpu_vs_cpu_oracle"] = vs_cpu(lp32, t32)
     for dt in args.dtypes.split(","):
         lp, t = run(dt)
         bad = [i for i, (a, b) in enumerate(zip(t, t32)) if a != b]
@@ -80,6 +89,8 @@ def main():
         out[dt] = {"strings_differ": len(bad), "argmax_agree": float((~flips).float().mean()),
                    "max_abs_err": float((lp - lp32).abs().max()), "steps_argmax_differ": int(flips.sum()),
                    "largest_f32_margin_at_a_flip": float(margin[flips].max()) if flips.any() else 0.0}
+        if ref_lp is not None:
+            out[dt + "_gpu_vs_cpu_oracle"] = vs_cpu(lp, t)
     # detector: binary-map error of the low-precision modes on full-size pages
     dsd = weights.make_det_state_dict(seed=1234)
     from ocr_vi_invoice_amd.pipeline import normalize_for_det
@@ -101,24 +112,27 @@ def main():
         spec.loader.exec_module(bench)
         torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
         n = args.cpu_det_pages
-        gpu = DBNetPP(pretrained=False, state_dict=dsd, dtype="f32", device=dev)(x[:n])
-        worst, rect_equal = {}, True
+        refs = [dbnet_cpu.forward(dsd, x[i:i + 1].cpu()) for i in range(n)]
         pp = DBPostProcessor(0.3, 0.5, 1000, 1.6)
-        for i in range(n):
-            ref = dbnet_cpu.forward(dsd, x[i:i + 1].cpu())
-            for k in ("binary", "thresh", "thresh_binary"):
-                worst[k] = max(worst.get(k, 0.0), float((gpu[k][i:i + 1].cpu() - ref[k]).abs().max()))
-            add = np.zeros((960, 1280), np.float32)
-            for r in rects:
-                if r[0] == i:
-                    sx, sy, sw, sh = bench.shrink_box(*r[1:])
-                    add[sy:sy + sh, sx:sx + sw] = 0.75
-            ma = (add + np.float32(0.25) * gpu["binary"][i, 0].cpu().numpy()).astype(np.float32)
-            mb = (add + np.float32(0.25) * ref["binary"][0, 0].numpy()).astype(np.float32)
-            ra, _, _ = db_boxes_batch(ma[None], pp)
-            rb, _, _ = db_boxes_batch(mb[None], pp)
-            rect_equal = rect_equal and np.array_equal(ra, rb)
-        out["det_f32_gpu_vs_cpu_oracle_fullsize"] = {"pages": n, "max_abs_err": worst, "crop_rects_equal": bool(rect_equal)}
+        for dt in ["f32"] + [d for d in args.dtypes.split(",") if d != "f32"]:
+            gpu = DBNetPP(pretrained=False, state_dict=dsd, dtype=dt, device=dev)(x[:n])
+            worst, rect_equal = {}, True
+            for i in range(n):
+                ref = refs[i]
+                for k in ("binary", "thresh", "thresh_binary"):
+                    worst[k] = max(worst.get(k, 0.0), float((gpu[k][i:i + 1].cpu() - ref[k]).abs().max()))
+                add = np.zeros((960, 1280), np.float32)
+                for r in rects:
+                    if r[0] == i:
+                        sx, sy, sw, sh = bench.shrink_box(*r[1:])
+                        add[sy:sy + sh, sx:sx + sw] = 0.75
+                ma = (add + np.float32(0.25) * gpu["binary"][i, 0].cpu().numpy()).astype(np.float32)
+                mb = (add + np.float32(0.25) * ref["binary"][0, 0].numpy()).astype(np.float32)
+                ra, _, _ = db_boxes_batch(ma[None], pp)
+                rb, _, _ = db_boxes_batch(mb[None], pp)
+                rect_equal = rect_equal and np.array_equal(ra, rb)
+            out[f"det_{dt}_gpu_vs_cpu_oracle_fullsize"] = {"pages": n, "max_abs_err": worst, "crop_rects_equal": bool(rect_equal)}
+            del gpu
     print(json.dumps(out, indent=1))
 
 
