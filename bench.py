@@ -34,9 +34,13 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3, "f16x2": 157.3}  # dense MFMA peaks, MI355X_MICROARCH.md (f16x2: see roofline_of)
+# Dense MFMA peaks (MI355X_MICROARCH.md), in TFLOP/s of the ALGORITHMIC product 2 M N K.  f16x2 forms every product from four 16-bit
+# partial products (hi hi, hi lo, lo hi, lo lo: two v_mfma_f32_16x16x32_f16 per 16 k), so its matrix-pipe roof for algorithmic FLOPs is
+# a quarter of the 16-bit peak; the fp32 MFMA peak (what the exact-fp32 mode is priced against) is quoted beside it.
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3, "f16x2": 625.0}
 PEAK_HBM_GBS = 8000.0
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
+PARITY_MODES = ("f16x2", "f32")       # modes whose CTC strings equal the CPU reference's (tests/test_gpu_parity_modes.py)
 
 
 def parse():
@@ -45,10 +49,11 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--dtype", default=None, choices=["bf16", "f16", "f32", "f16x2"],
-                    help="MFMA operand type of both models for the headline.  Default: f32 (the parity mode, whose CTC strings equal the CPU "
-                         "reference's) followed by the --also mode; giving --dtype runs that one mode only")
-    ap.add_argument("--also", default="f16", choices=["f16", "bf16", "none"],
-                    help="16-bit throughput mode measured after the headline in the same process and reported as `throughput_mode`")
+                    help="operand type of both models for the headline.  Default: f16x2 (fp32-equivalent operands as two fp16 halves on the 16-bit "
+                         "matrix pipe: CTC strings equal the CPU reference's), followed by the --also modes; giving --dtype runs that one mode only")
+    ap.add_argument("--also", default="f32,f16",
+                    help="comma list of further modes measured after the headline in the same process on the same inputs (f32 = exact fp32 MFMA, "
+                         "reported as `exact_fp32_mode`; f16 / bf16 = 16-bit throughput mode, reported as `throughput_mode`), or `none`")
     ap.add_argument("--workload", default="e2e", choices=["e2e", "det", "rec"])
     ap.add_argument("--batch", type=int, default=64, help="invoices per rank per step (BASELINE.json configs[3])")
     ap.add_argument("--lines", type=int, default=30)
@@ -154,7 +159,9 @@ class E2E:
         self.devi = torch.device(dev).index or 0
         # pipeline2.py:213-216,254-259 defaults: thresh 0.3, box_thresh 0.5, unclip 1.6, min_area 10
         self.pp = DBPostProcessor(thresh=0.3, box_thresh=0.5, max_candidates=1000, unclip_ratio=1.6)
-        self.post_threads = args.post_threads or max(2, usable_cores(16))
+        # host threads of this rank's post-processing stage: this rank's share of the cores the job may really use (affinity mask cut by
+        # the cgroup quota), at most 16 -- eight ranks on one host must not each take sixteen
+        self.post_threads = args.post_threads or max(2, min(16, usable_cores(1 << 20) // max(1, n_ranks_on_host)))
         self.detected = args.boxes == "detected" and args.workload == "e2e"
 
     # ---- inputs
@@ -507,8 +514,10 @@ def run_mode(args, dtype, dev, cdev, det_blob, rec_blob, images_u8, boxes, local
     if dist:
         dist.barrier()
     dt = time.perf_counter() - t0
+    rank_dt = [dt]
     if dist:
-        from ocr_vi_invoice_amd.dist import max_over_ranks
+        from ocr_vi_invoice_amd.dist import gather_over_ranks, max_over_ranks
+        rank_dt = gather_over_ranks(dt, cdev, dist)      # every rank's own time: load imbalance would show here
         dt = max_over_ranks(dt, cdev, dist)
     assert len(done) == a.steps, (len(done), a.steps)
     last_rects, texts, counts = done[-1]
@@ -521,7 +530,7 @@ def run_mode(args, dtype, dev, cdev, det_blob, rec_blob, images_u8, boxes, local
         pipe.eager_pass(last_rects)
         _lib.check(lib.ocrvi_prof_enable(0))
         prof = _lib.prof_report()
-    out = {"dt": dt, "rects": last_rects, "texts": texts, "counts": counts, "prof": prof, "detected": pipe.detected,
+    out = {"dt": dt, "rank_dt": rank_dt, "rects": last_rects, "texts": texts, "counts": counts, "prof": prof, "detected": pipe.detected,
            "post_threads": pipe.post_threads, "images": pipe.images}
     if pipe.detected:   # bytes the post-processing stage pulls over PCIe per page (whole map, or mask + component table + box values)
         out["d2h_bytes_per_page"] = (int(pipe.d2h_bytes / ((a.steps + a.warmup) * a.batch)) if getattr(pipe, "dcomp", None) is not None
@@ -556,6 +565,9 @@ def roofline_of(prof, dtype):
         except (OSError, ValueError, KeyError):
             pass
     r = roof(name, d)
+    if dtype == "f16x2" and r["bound"] == "mfma":
+        r.update({"peak_note": "2500 TFLOP/s dense 16-bit MFMA / 4 partial products per product", "executed_16bit_mfma_tflops": round(4 * r["achieved"], 1),
+                  "frac_of_16bit_mfma_peak_executed": round(4 * r["achieved"] / 2500.0, 4), "frac_of_fp32_mfma_peak": round(r["achieved"] / 157.3, 4)})
     r.update({"traffic": traffic, "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"], 1), "launches": d["launches"],
               "avg_ms": round(d["ms"] / d["launches"], 4), "algorithmic_flops_per_launch": round(d["flops"] / d["launches"], 1),
               "timed_by": "HIP events on the launch stream around every launch, one sequential eager pass after the timed region"})
@@ -582,15 +594,21 @@ def main():
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (python bench.py --gpus N does it itself)")
-    # The headline is quoted in the mode whose CTC strings equal the CPU reference's: fp32 MFMA (DESIGN.md section 4 shows why no
-    # 16-bit mode can on the random-weight model).  The 16-bit throughput mode runs in the same process and is reported beside it.
-    primary = args.dtype or "f32"
-    secondary = None if (args.dtype is not None or args.also == "none" or args.also == primary) else args.also
+    # The headline is quoted in a mode whose CTC strings equal the CPU reference's: f16x2 (fp32-equivalent operands on the 16-bit matrix
+    # pipe; the gate it passed is in DESIGN.md section 4).  The exact-fp32 MFMA mode and a plain 16-bit throughput mode run in the same
+    # process on the same inputs and are reported beside it.
+    primary = args.dtype or "f16x2"
+    others = [] if (args.dtype is not None or args.also == "none") else [m for m in args.also.split(",") if m and m != primary]
+    for m in others:
+        if m not in PEAK_TFLOPS:
+            raise SystemExit(f"bench.py: unknown mode {m!r} in --also")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     # Rehearsal switch for a 1-GPU box: OCRVI_BENCH_REHEARSE=1 puts every rank on cuda:0 and uses gloo for the (CPU-side) collectives.
     rehearse = os.environ.get("OCRVI_BENCH_REHEARSE") == "1"
     if rehearse:
         local = 0
+    elif torch.cuda.device_count() <= local:      # (device_count() does not initialise the GPU)
+        raise SystemExit(f"bench.py: rank {rank} wants cuda:{local} but only {torch.cuda.device_count()} device(s) are visible: one rank per GPU")
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     cdev = "cpu" if rehearse else dev           # device the collectives run on
@@ -628,7 +646,7 @@ def main():
     lib = _lib.load()
 
     m1 = run_mode(args, primary, dev, cdev, det_blob, rec_blob, images_u8, boxes, local_world, dist, lib)
-    m2 = run_mode(args, secondary, dev, cdev, det_blob, rec_blob, images_u8, boxes, local_world, dist, lib) if secondary else None
+    extra = [(m, run_mode(args, m, dev, cdev, det_blob, rec_blob, images_u8, boxes, local_world, dist, lib)) for m in others]
 
     if rank == 0:
         last_rects, texts, counts = m1["rects"], m1["texts"], m1["counts"]
@@ -638,6 +656,11 @@ def main():
         unit = "crops/s" if args.workload == "rec" else "images/s"
         boxes_note = ("boxes = DB post-processing (host, in the timed region) of the detector's binary map blended with synthetic text kernels"
                       if m1["detected"] else "boxes=synthetic-gt, DB post-processing not timed")
+
+        def rank_spread(m):      # every rank's own time for the timed region (ms per step): imbalance across ranks shows here
+            per = [round(t / args.steps * 1e3, 3) for t in m["rank_dt"]]
+            return {"min": min(per), "max": max(per), "per_rank": per}
+
         res = {
             "metric": metric, "value": round(world * units_per_step * args.steps / m1["dt"], 3), "unit": unit,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(m1["dt"] / args.steps * 1e3, 3),
@@ -648,12 +671,17 @@ def main():
                        "global_batch": world * args.batch, "det_chunk": args.det_chunk, "rec_batch": args.rec_batch,
                        "crops_per_step_rank0": n_crops, "boxes_per_page_min_max": [min(counts), max(counts)] if counts else None,
                        "weights": "seeded synthetic (no checkpoint ships)",
+                       "arithmetic": {"f16x2": "every GEMM operand as two fp16 halves (x = hi + lo), all four partial products on v_mfma_f32_16x16x32_f16, "
+                                               "fp32 accumulation; fp32 inputs, outputs, biases, residual stream, softmax and LayerNorm (DESIGN.md section 4)",
+                                      "f32": "fp32 operands on v_mfma_f32_16x16x4_f32 (an fp32 fmaf chain)",
+                                      "f16": "plain fp16 operands, fp32 accumulation", "bf16": "plain bf16 operands, fp32 accumulation"}[primary],
                        "launch": ("eager" if args.no_graph else "hipGraph replay") +
                                  (", one stream, one step at a time (--no-overlap)" if args.no_overlap else
                                   ", det stream || host post-processing || rec stream; recogniser batches filled across steps, one padded batch at the flush"),
                        "post_process": {"in_timed_region": bool(m1["detected"]), "host_threads": m1["post_threads"], "mode": args.post,
                                         "d2h_bytes_per_page": m1.get("d2h_bytes_per_page")},
                        "parallelism": f"replicas x{world}, images sharded, no collective"},
+            "ms_per_step_by_rank": rank_spread(m1),
         }
         if bcast_ms is not None:
             res["weight_broadcast_ms"] = round(bcast_ms, 2)
@@ -665,7 +693,8 @@ def main():
         if args.workload != "det" and last_rects is not None and (not args.no_parity_check or not args.no_cpu_baseline):
             from ocr_vi_invoice_amd.pipeline import preprocess_crops
             crops_all = preprocess_crops(m1["images"], last_rects, (48, 320))
-        if args.workload != "det" and not args.no_parity_check and crops_all is not None and primary != "f32":
+        have_f32 = any(m == "f32" for m, _ in extra)
+        if args.workload != "det" and not args.no_parity_check and crops_all is not None and primary != "f32" and not have_f32:
             from ocr_vi_invoice_amd import SVTRv2
             ref = SVTRv2("base", blob=rec_blob, dtype="f32", device=dev)
             t32 = []
@@ -674,20 +703,22 @@ def main():
             res["cer_vs_f32_mode"] = round(cer(texts, t32), 5)
             res["strings_differ_vs_f32_mode"] = [sum(a != b for a, b in zip(texts, t32)), len(t32)]
             del ref
-        if m2 is not None:
-            tm = {"dtype": secondary, "value": round(world * units_per_step * args.steps / m2["dt"], 3), "unit": unit,
+        for mode, m2 in extra:
+            tm = {"dtype": mode, "value": round(world * units_per_step * args.steps / m2["dt"], 3), "unit": unit,
                   "ms_per_step": round(m2["dt"] / args.steps * 1e3, 3), "steps": args.steps, "warmup": args.warmup,
-                  "note": "same process, same inputs, same timed region as the headline; NOT string-identical to the CPU reference on the "
-                          "random-weight model (DESIGN.md section 4)"}
+                  "ms_per_step_by_rank": rank_spread(m2),
+                  "note": ("same process, same inputs, same timed region as the headline; " +
+                           ("fp32 operands on the fp32 MFMA: the arithmetic the reference's CPU path uses" if mode in PARITY_MODES else
+                            "NOT string-identical to the CPU reference on the random-weight model (DESIGN.md section 4)"))}
             if m2["prof"]:
-                tm["roofline"], tm["roofline_by_kernel"], tm["model_mfma_tflops"] = roofline_of(m2["prof"], secondary)
+                tm["roofline"], tm["roofline_by_kernel"], tm["model_mfma_tflops"] = roofline_of(m2["prof"], mode)
             if args.workload != "det" and m2["texts"] is not None and texts is not None:
                 same_rects = m2["rects"] is not None and last_rects is not None and np.array_equal(m2["rects"], last_rects)
                 tm["crop_rects_equal_headline"] = bool(same_rects)
                 if same_rects:
                     tm["cer_vs_headline_strings"] = round(cer(m2["texts"], texts), 5)
                     tm["strings_differ_vs_headline"] = [sum(x != y for x, y in zip(m2["texts"], texts)), len(texts)]
-            res["throughput_mode"] = tm
+            res["exact_fp32_mode" if mode == "f32" else ("throughput_mode" if mode not in PARITY_MODES else mode + "_mode")] = tm
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only
             cb, cer_cpu = cpu_baseline(args, det_sd, rec_sd, images_u8[0], crops_all, texts)
             res["cpu_baseline"] = cb

@@ -7,7 +7,8 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libocrvi.so")
+# (OCRVI_LIB: development aid -- an instrumented build of the same library, e.g. the ring-GEMM phase-stamp build tools/ring_prof.py uses)
+LIB_PATH = os.environ.get("OCRVI_LIB") or os.path.join(_HERE, "lib", "libocrvi.so")
 
 OCRVI_F32, OCRVI_BF16, OCRVI_F16, OCRVI_F16X2 = 0, 1, 2, 3
 DTYPES = {"f32": OCRVI_F32, "fp32": OCRVI_F32, "float32": OCRVI_F32, "bf16": OCRVI_BF16, "bfloat16": OCRVI_BF16,

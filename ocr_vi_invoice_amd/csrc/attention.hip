@@ -110,8 +110,9 @@ __global__ __launch_bounds__(NWV * 64) void attention_kernel(const T* __restrict
             for (int t = 0; t < MAXT; ++t) {
                 acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 const char* kr = Ksq + (t * 16 + lr) * KROW;
-                const uint4 kf[2] = {*(const uint4*)(kr + o0), *(const uint4*)(kr + o1)};
-                Mma<T>::run(kf, qf, acc[t]);
+                const uint4 kf0 = *(const uint4*)(kr + o0), kf1 = *(const uint4*)(kr + o1);
+                Mma<T>::half(kf0, qf[0], acc[t]);
+                Mma<T>::half(kf1, qf[1], acc[t]);
             }
         } else {
             uint4 qf = make_uint4(0, 0, 0, 0);

@@ -211,10 +211,13 @@ template <> struct Mma<f16_t> {
 };
 
 template <> struct Mma<f16x2_t> {   // operands are chunks [4 hi | 4 lo]: hh + ll, then lh + hl with the halves of `a` exchanged
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
     __device__ static inline void half(const uint4& a, const uint4& b, f32x4& c) {
-        const uint4 as = make_uint4(a.z, a.w, a.x, a.y);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, as), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+        // (register vectors, not uint4 structs: with the structs hipcc kept fragment arrays in scratch memory to form the swapped operand)
+        const u4v av = {a.x, a.y, a.z, a.w}, bv = {b.x, b.y, b.z, b.w};
+        const u4v as = __builtin_shufflevector(av, av, 2, 3, 0, 1);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, as), __builtin_bit_cast(f16x8, bv), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, bv), c, 0, 0, 0);
     }
     __device__ static inline void run(const uint4 (&a)[2], const uint4 (&b)[2], f32x4& c) {
         half(a[0], b[0], c);

@@ -53,6 +53,7 @@ struct ConvParams {
     int epi_lds = 0;       // stage the output tile through LDS and store whole rows (ST_NHWC only; set by launch_conv)
     int res_in_store = 0;  // fp32 out + fp32 residual, no activation: add the residual in the coalesced store phase
     int patch_lw = 7;      // dcn_pipe: a tile is a (128 >> patch_lw) x (1 << patch_lw) patch of output pixels
+    unsigned out_bytes = 0;   // gemm_ring: bytes of the output tensor the stores may touch (buffer descriptor range; filled by launch_gemm_ring)
     float wscale = 1.f;    // f16x2: the weights are stored multiplied by 2^s (one power of two per layer, chosen by the packer so that their
                            // lo halves are normal fp16 numbers); every epilogue multiplies the accumulator by wscale = 2^-s (exact)
 };
@@ -66,6 +67,12 @@ __device__ __forceinline__ int fastdiv(int n, unsigned long long mg) { return (i
 
 // Resident workgroups per CU the launcher sizes the persistent grid for (bounded by VGPRs: 168 / 112 / 88 per lane).
 template <int AMODE, int BM, int BN> struct ConvOcc { static constexpr int value = AMODE == AM_DCN ? 2 : (BN >= 128 ? 3 : (BN >= 64 ? 4 : 5)); };
+// ... per operand type: the f16x2 build keeps a half-swapped copy of every weight fragment (Mma<f16x2_t>), which does not fit 168 VGPRs at
+// 128 x 128 (37 spilled dwords measured): two workgroups per CU there
+// the 16-bit builds of the 128 x 128 tile spilled 10-12 VGPRs at three workgroups per CU (168 registers): two per CU as well
+template <typename T, int AMODE, int BM, int BN> struct ConvOccT {
+    static constexpr int value = (!IsF32<T>::value && BN >= 128 && AMODE != AM_DCN) ? 2 : ConvOcc<AMODE, BM, BN>::value;
+};
 
 // Persistent implicit-GEMM kernel.  A workgroup (4 waves) walks output tiles  first, first+G, first+2G, ...  One LDS stage
 // (A tile + W tile, 128 B of K per row); global loads for the NEXT K-step -- or the next TILE's first K-step -- are issued
@@ -79,7 +86,7 @@ template <int AMODE, int BM, int BN> struct ConvOcc { static constexpr int value
 // epilogue; +~40 VGPRs); 2 = persistent, tiles strictly one after another (no extra registers; tile i's stores drain under
 // tile i+1's loads).
 template <typename T, int AMODE, int BM, int BN, int WM, int WN, int PERSIST>
-__global__ __launch_bounds__(256, (ConvOcc<AMODE, BM, BN>::value)) void conv_gemm_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, (ConvOccT<T, AMODE, BM, BN>::value)) void conv_gemm_kernel(const ConvParams p) {
     constexpr int EPC = TypeInfo<T>::EPC;  // elements per 16-byte chunk
     constexpr int BKE = 8 * EPC;           // elements per K-step (128 bytes)
     constexpr int TM = BM / WM, TN = BN / WN;

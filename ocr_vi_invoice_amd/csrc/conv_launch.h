@@ -25,11 +25,19 @@ static int launch_tile(const ConvParams& p, hipStream_t stream) {
     return OCRVI_OK;
 }
 
+template <typename T, int BM, int NW, int SPS, bool F32O, bool C3, int BN, int ACT>
+static int launch_ring_act(const ConvParams& p, int grid, hipStream_t stream) {
+    constexpr int smem = 3 * (BM + BN) * 128 + 512;  // ring + bias
+    auto kern = gemm_ring_kernel<T, BM, NW, SPS, F32O, C3, BN, false, ACT>;
+    OCRVI_TRY(ensure_max_smem((const void*)kern, smem));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), smem, stream, p);
+    OCRVI_HIP(hipGetLastError());
+    return OCRVI_OK;
+}
+
 template <typename T, int BM, int NW, int SPS, bool F32O, bool C3, int BN = 128>
 static int launch_ring_f(const ConvParams& p, int grid, hipStream_t stream) {
     constexpr int smem = 3 * (BM + BN) * 128 + 512;  // ring + bias
-    auto kern = gemm_ring_kernel<T, BM, NW, SPS, F32O, C3, BN>;
-    OCRVI_TRY(ensure_max_smem((const void*)kern, smem));
 #ifdef OCRVI_RING_PROF_BUILD
     static const bool prof = getenv("OCRVI_RING_PROF") && atoi(getenv("OCRVI_RING_PROF"));
     if (prof) {  // development aid: cycle breakdown per phase, printed per launch (synchronises)
@@ -53,9 +61,14 @@ static int launch_ring_f(const ConvParams& p, int grid, hipStream_t stream) {
         return OCRVI_OK;
     }
 #endif
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), smem, stream, p);
-    OCRVI_HIP(hipGetLastError());
-    return OCRVI_OK;
+    // one instantiation per activation (compile-time epilogue: no run-time selects in the slice groups)
+    switch (p.act) {
+        case ACT_NONE: return launch_ring_act<T, BM, NW, SPS, F32O, C3, BN, ACT_NONE>(p, grid, stream);
+        case ACT_RELU: return launch_ring_act<T, BM, NW, SPS, F32O, C3, BN, ACT_RELU>(p, grid, stream);
+        case ACT_GELU: return launch_ring_act<T, BM, NW, SPS, F32O, C3, BN, ACT_GELU>(p, grid, stream);
+    }
+    set_error("gemm_ring: unknown activation %d", p.act);
+    return OCRVI_EINVAL;
 }
 
 template <typename T, int BM, int NW, int SPS>
@@ -77,6 +90,10 @@ template <typename T>
 int launch_gemm_ring(const ConvParams& p_in, int amode, hipStream_t stream) {
     ConvParams p = p_in;
     OCRVI_TRY(ring_pages(&p.zero_page, &p.dump_page));
+    {   // range of the output buffer descriptor (gemm_ring_eligible has checked that it is below 4 GiB)
+        const size_t osz = (sizeof(T) == 4 || p.out_f32) ? 4 : 2;
+        p.out_bytes = (unsigned)(((size_t)(p.M - 1) * p.ldo + p.out_coff + p.N_g) * osz);
+    }
     int n_cu = 0;
     OCRVI_TRY(device_cus(&n_cu));
     const int bn = p.Np % 128 == 0 ? 128 : 64;  // 64-channel layers: a 256x64 tile (16-bit types only, checked by gemm_ring_eligible)
@@ -90,7 +107,10 @@ int launch_gemm_ring(const ConvParams& p_in, int amode, hipStream_t stream) {
     // nk = 2..3 with a 16-bit output: 256-row tiles with two slice groups of two slices (the fp32-output build of that shape spills)
     const bool mid256 = mid && nk >= 2 && nk < 4 && !f32o && big_m && amode == AM_CONV1;
     // (fp32 GEMMs -- the parity mode -- stay on 128-row tiles: their 256-row build does not fit the register file without a spill)
-    const int bm = bn == 64 ? 256 : ((sizeof(T) == 2 && ((nk >= 4 && big_m) || mid256)) ? 256 : 128);
+    // (f16x2: 4-byte operands like fp32, but its 256-row build -- 255 VGPRs, no scratch -- fits, and the kernel is bound by the bytes it
+    // streams per FLOP, not by the matrix pipe: 256 x 128 tiles move 2/3 of the bytes of 128 x 128 ones)
+    const bool wide_ok = sizeof(T) == 2 || IsSplit<T>::value;
+    const int bm = bn == 64 ? 256 : ((wide_ok && ((nk >= 4 && big_m) || mid256)) ? 256 : 128);
     // one persistent workgroup per CU; a workgroup keeps its column tile, so the grid is Gm row-tile lanes x ntiles, with Gm chosen
     // for equal row-tile counts
     const int mtiles = cdiv(p.M, bm);
@@ -105,7 +125,7 @@ int launch_gemm_ring(const ConvParams& p_in, int amode, hipStream_t stream) {
     if constexpr (sizeof(T) == 2) {
         if (bm == 256 && mid256) return launch_ring_f<T, 256, 8, 2, false, false>(p, grid, stream);
     }
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (sizeof(T) == 2 || IsSplit<T>::value) {
         if (bm == 256) return launch_ring_cfg<T, 256, 8, 1>(p, amode, grid, stream);
     }
     return launch_ring_cfg<T, 128, 8, 2>(p, amode, grid, stream);  // MI = 2: one group

@@ -87,7 +87,7 @@ __device__ __forceinline__ void bind16(u32x4& r) { asm volatile("" : "+v"(r)); }
 // cycles spent in wait+barrier / issue / ds_read+MFMA / epilogue work and adds them into p.out2 (uint64[4]) at exit.
 template <int I> struct IC { static constexpr int value = I; };
 
-template <typename T, int BM, int NW, int SPS, bool F32O, bool C3 = false, int BN = 128, bool PROF = false>
+template <typename T, int BM, int NW, int SPS, bool F32O, bool C3 = false, int BN = 128, bool PROF = false, int ACT = -1>
 __global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams p) {
     constexpr int EPC = TypeInfo<T>::EPC, BKE = 8 * EPC;
     static_assert(BN == 128 || BN == 64, "column tile");
@@ -234,15 +234,23 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams 
     static_assert(G <= 8 && G <= 2 * NI, "one DMA piece per weight-fragment row of a step");
     constexpr bool SPREAD = !(F32O && MI >= 4);
 
+    // the activation is a template parameter (the launcher instantiates the three): no run-time selects inside the slice groups
     auto activate = [&](float (&v)[4]) {
-        if (p.act == ACT_RELU) {
+        const int act = ACT >= 0 ? ACT : p.act;
+        if (act == ACT_RELU) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-        } else if (p.act == ACT_GELU) {
+        } else if (act == ACT_GELU) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
         }
     };
+    // Output stores go through a buffer descriptor: 32-bit byte offsets from the tensor base (one multiply per row instead of 64-bit
+    // pointer arithmetic per fragment) and the hardware's range check drops the lanes past M or N_g -- the instruction still issues, so
+    // the counted vmcnt protocol keeps its exact store count without a dump page.  (host contract: the output is < 4 GiB)
+    const int osz_b = (F32O || sizeof(T) == 4) ? 4 : 2;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.out_bytes, 0x00020000);
+    constexpr unsigned OOB = 0xfffffff0u;
     auto a_row = [&](int a) { return f32o ? 16 * a : 32 * (a >> 1) + 4 * (a & 1); };
     // channel (inside the wave's 64) of acc[a][.][0] for this lane
     auto ch_of = [&](int a) { return f32o ? 16 * a + 4 * g : 32 * (a >> 1) + 8 * g + 4 * (a & 1); };
@@ -298,19 +306,23 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams 
     // bias / activation / residual / store of slice group GRP of the parked tile (accumulators pnd, row tile pmt).  Exactly S32 / S16
     // store instructions per wave: out-of-range lanes write to the dump page instead of being skipped.
     auto run_group = [&](auto GRP, Acc& pnd, int pmt) {
-        // one accumulator fragment: bias, activation and (fp32) residual; chunks are fenced with sched_barrier so that the scheduler
-        // does not interleave all of a group's GELU polynomials (that costs more registers than the kernel has)
+        constexpr int q0 = decltype(GRP)::value * SPS;
+        // the bias of the wave's four fragments: all LDS reads in flight together, one wait (the operand fragments are dead here, so the
+        // sixteen registers are free)
+        float4 bv[NI];
+#pragma unroll
+        for (int a = 0; a < NI; ++a) bv[a] = *(const float4*)(bias_s + wn * TN + ch_of(a));
+        // one accumulator fragment: weight scale, bias, activation (fragments are fenced with sched_barrier so that the scheduler does not
+        // interleave all of a group's GELU polynomials: that costs more registers than the kernel has)
         auto frag = [&](float (&v)[4], const f32x4& c, int a) {
-            const float4 bv = *(const float4*)(bias_s + wn * TN + ch_of(a));
-            v[0] = unscale<T>(c[0], p.wscale) + bv.x; v[1] = unscale<T>(c[1], p.wscale) + bv.y;
-            v[2] = unscale<T>(c[2], p.wscale) + bv.z; v[3] = unscale<T>(c[3], p.wscale) + bv.w;
+            v[0] = unscale<T>(c[0], p.wscale) + bv[a].x; v[1] = unscale<T>(c[1], p.wscale) + bv[a].y;
+            v[2] = unscale<T>(c[2], p.wscale) + bv[a].z; v[3] = unscale<T>(c[3], p.wscale) + bv[a].w;
             if (p.res_post) activate(v);
         };
 #pragma unroll
         for (int j = 0; j < SPS; ++j) {
-            constexpr int q0 = decltype(GRP)::value * SPS;
             const int m = pmt * BM + wm * TM + (q0 + j) * 16 + lr;
-            const size_t row_off = (size_t)m * p.ldo + p.out_coff + nb;
+            const unsigned row_b = m < p.M ? ((unsigned)m * (unsigned)p.ldo + (unsigned)(p.out_coff + nb)) * (unsigned)osz_b : OOB;
             if constexpr (F32O) {
 #pragma unroll
                 for (int a = 0; a < NI; ++a) {
@@ -329,9 +341,15 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams 
                     }
                     if (!p.res_post) activate(v);
                     const int c = ch_of(a);
-                    float* o = (m < p.M && nb + c < p.N_g) ? (float*)p.out + row_off + c : (float*)p.dump_page + lane * 4;
-                    if (IsSplit<T>::value && !p.out_f32) *(uint4*)o = Chunk<T>::pack(v);
-                    else *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+                    const unsigned off = (row_b != OOB && nb + c < p.N_g) ? row_b + (unsigned)c * 4u : OOB;
+                    u32x4 pk;
+                    if (IsSplit<T>::value && !p.out_f32) {
+                        const uint4 e = Chunk<T>::pack(v);
+                        pk = (u32x4){e.x, e.y, e.z, e.w};
+                    } else {
+                        pk = (u32x4){__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(pk, orsrc, off, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
@@ -354,14 +372,14 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams 
                         activate(v1);
                     }
                     const int c = 32 * h + 8 * g;
-                    union { T e[8]; uint4 u; } pk;
+                    union { T e[8]; u32x4 u; } pk;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         pk.e[r] = from_f32<T>(v0[r]);
                         pk.e[4 + r] = from_f32<T>(v1[r]);
                     }
-                    T* o = (m < p.M && nb + c < p.N_g) ? (T*)p.out + row_off + c : (T*)p.dump_page + lane * 8;
-                    *(uint4*)o = pk.u;
+                    const unsigned off = (row_b != OOB && nb + c < p.N_g) ? row_b + (unsigned)c * 2u : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(pk.u, orsrc, off, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }

@@ -250,6 +250,8 @@ bool gemm_ring_eligible(const ConvParams& p, int amode, int dtype) {
     if (p.N_g % og != 0 || p.ldo % og != 0 || p.out_coff % og != 0 || ((uintptr_t)p.out & 15) != 0) return false;
     if (p.res_mode != RES_NONE && (rf32 != of32 || p.ldr % og != 0 || ((uintptr_t)p.res & 15) != 0)) return false;
     if (p.bias && ((uintptr_t)p.bias & 15) != 0) return false;
+    // the epilogue addresses the output with 32-bit byte offsets through a buffer descriptor
+    if (((size_t)(p.M - 1) * p.ldo + p.out_coff + p.N_g) * (of32 ? 4 : 2) >= ((size_t)1 << 32) - 65536) return false;
     return true;
 }
 

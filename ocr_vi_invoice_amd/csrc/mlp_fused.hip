@@ -386,15 +386,14 @@ static int launch_mlp(const MlpParams& p, hipStream_t s) {
 }
 
 template <typename T> static int mlp_dt(const MlpParams& p, int D, hipStream_t s) {
-    // 8 waves of 16 tokens (two per SIMD) beat 4 waves of 32 (one per SIMD, the layout the register budget was first designed around)
-    // by 8-9 % at every D (MI355X, 256 crops: 223 -> 202, 284 -> 266, 271 -> 248 us): a wave's ring waits and its GELU stretches fall
-    // under the other wave's MFMAs, which outweighs reading every weight fragment from LDS twice as often.  OCRVI_MLP_TB=2: the old layout.
-    // (D = 128 would also fit two workgroups per CU, but that 256-register build of the 4-wave layout spilled and was measured wrong.)
-    static const bool tb2 = getenv("OCRVI_MLP_TB") && atoi(getenv("OCRVI_MLP_TB")) == 2;
+    // 8 waves of 16 tokens (two per SIMD: TB = 1) beat 4 waves of 32 (one per SIMD, the layout the register budget was first designed
+    // around) by 8-9 % at every D (MI355X, 256 crops: 223 -> 202, 284 -> 266, 271 -> 248 us): a wave's ring waits and its GELU stretches
+    // fall under the other wave's MFMAs, which outweighs reading every weight fragment from LDS twice as often.  The 4-wave layout is no
+    // longer instantiated: its D = 384 build spilled 25 VGPRs into a kernel whose LDS-DMA ring is synchronised by hand-counted vmcnt.
     switch (D) {
-        case 128: return tb2 ? launch_mlp<T, 128, 1, 9, 2>(p, s) : launch_mlp<T, 128, 1, 9, 1>(p, s);    // ring: 9 units of 16 KiB
-        case 256: return tb2 ? launch_mlp<T, 256, 1, 4, 2>(p, s) : launch_mlp<T, 256, 1, 4, 1>(p, s);    //       4 units of 32 KiB
-        case 384: return tb2 ? launch_mlp<T, 384, 1, 3, 2>(p, s) : launch_mlp<T, 384, 1, 3, 1>(p, s);    //       3 units of 48 KiB
+        case 128: return launch_mlp<T, 128, 1, 9, 1>(p, s);    // ring: 9 units of 16 KiB
+        case 256: return launch_mlp<T, 256, 1, 4, 1>(p, s);    //       4 units of 32 KiB
+        case 384: return launch_mlp<T, 384, 1, 3, 1>(p, s);    //       3 units of 48 KiB
     }
     set_error("mlp_fused: D=%d unsupported", D);
     return OCRVI_EINVAL;

@@ -86,3 +86,11 @@ def max_over_ranks(seconds: float, device, dist) -> float:
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def gather_over_ranks(value: float, device, dist) -> List[float]:
+    """Every rank's value, in rank order, on every rank (the per-rank step times bench.py reports beside their maximum)."""
+    t = torch.zeros(dist.get_world_size(), dtype=torch.float64, device=device)
+    t[dist.get_rank()] = value
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(v) for v in t.tolist()]

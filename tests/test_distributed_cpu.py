@@ -8,7 +8,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from ocr_vi_invoice_amd import weights
-from ocr_vi_invoice_amd.dist import broadcast_blobs, broadcast_weights, flatten_state_dicts, max_over_ranks, shard_range
+from ocr_vi_invoice_amd.dist import broadcast_blobs, broadcast_weights, flatten_state_dicts, gather_over_ranks, max_over_ranks, shard_range
 
 
 def _free_port():
@@ -28,6 +28,7 @@ def _worker(rank, world, port, q):
         same = bool(torch.equal(flatten_state_dicts(sds), want))
         dtype_ok = sds[0]["stem.bn1.num_batches_tracked"].dtype == torch.long
         slow = max_over_ranks(1.0 + rank, "cpu", dist)      # the slowest rank defines the step time
+        per_rank = gather_over_ranks(1.0 + rank, "cpu", dist)   # ... and every rank's own time is reported beside it (bench.py: ms_per_step_by_rank)
         lo, hi = shard_range(13, rank, world)
         # the designed collective: rank 0 folds + packs, everybody receives the same bytes; other ranks build nothing
         mine = None
@@ -36,7 +37,7 @@ def _worker(rank, world, port, q):
         got, bms = broadcast_blobs(mine, "cpu", dist)
         want_blob = weights.pack_blob(weights.fold_rec(weights.make_rec_state_dict("tiny", seed=100), "tiny"))
         blob_ok = got[0] == want_blob and got[1] == b"second-blob" and bms >= 0
-        q.put((rank, same, dtype_ok, slow, lo, hi, ms >= 0 and blob_ok))
+        q.put((rank, same, dtype_ok, slow, lo, hi, ms >= 0 and blob_ok and per_rank == [1.0, 2.0]))
     finally:
         dist.destroy_process_group()
 

@@ -13,7 +13,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PARITY_DTYPES = ["f32"]      # modes that must reproduce the CPU oracle (1e-3 maps / log-probs, identical rectangles and strings)
+PARITY_DTYPES = ["f32", "f16x2"]      # modes that must reproduce the CPU oracle (1e-3 maps / log-probs, identical rectangles and strings)
 
 
 def _bench_module():

@@ -12,14 +12,19 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+# Modes that must reproduce the reference's fp32 results (north_star: maps / logits within 1e-3, CTC strings identical): fp32 operands on
+# the fp32 MFMA, and f16x2 = every operand as two fp16 halves with all four partial products on the 16-bit MFMA (include/ocrvi.h).
+PARITY = ["f32", "f16x2"]
 
+
+@pytest.mark.parametrize("dt", PARITY)
 @pytest.mark.parametrize("name", ["rec_tiny_32x256", "rec_base_48x320"])
-def test_svtrv2_f32_matches_reference_golden(golden_dir, name):
+def test_svtrv2_f32_matches_reference_golden(golden_dir, name, dt):
     from ocr_vi_invoice_amd import SVTRv2, weights
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     variant = str(g["variant"])
     sd = weights.make_rec_state_dict(variant, seed=int(g["seed"]))
-    m = SVTRv2(variant, state_dict=sd, dtype="f32")
+    m = SVTRv2(variant, state_dict=sd, dtype=dt)
     x = torch.from_numpy(g["x"]).cuda()
     bn, frm = m.debug_features(x)
     np.testing.assert_allclose(bn.cpu().numpy(), g["backbone_norm"], atol=1e-3)
@@ -61,14 +66,16 @@ def test_svtrv2_small_variant_matches_oracle_and_lowp_budgets():
     x = torch.from_numpy(synth.pad_crop_batch(synth.make_crops(13, 6, 48, 320), 48, 320))
     ref = svtrv2_cpu.forward(sd, x, "small")
     want = Tokenizer().decode(svtrv2_cpu.greedy_ids(ref))
-    m = SVTRv2(state_dict=sd, dtype="f32")                                  # constructor default: 'small'
-    assert m.variant == "small" and m.dims == [96, 192, 256]
-    lp = m(x.cuda())
-    assert lp.shape == (80, 6, 232)
-    np.testing.assert_allclose(lp.cpu().numpy(), ref.numpy(), atol=1e-3)
-    assert m.decode_probs(lp) == want and m.decode_greedy(x.cuda()) == want
     x32 = torch.from_numpy(synth.pad_crop_batch(synth.make_crops(14, 3, 32, 256), 32, 256))      # the pipeline's default crop size (pipeline2.py:219-220)
-    np.testing.assert_allclose(m(x32.cuda()).cpu().numpy(), svtrv2_cpu.forward(sd, x32, "small").numpy(), atol=1e-3)
+    ref32 = svtrv2_cpu.forward(sd, x32, "small")
+    for dt in PARITY:
+        m = SVTRv2(state_dict=sd, dtype=dt)                               # constructor default: 'small'
+        assert m.variant == "small" and m.dims == [96, 192, 256]
+        lp = m(x.cuda())
+        assert lp.shape == (80, 6, 232)
+        np.testing.assert_allclose(lp.cpu().numpy(), ref.numpy(), atol=1e-3, err_msg=dt)
+        assert m.decode_probs(lp) == want and m.decode_greedy(x.cuda()) == want
+        np.testing.assert_allclose(m(x32.cuda()).cpu().numpy(), ref32.numpy(), atol=1e-3, err_msg=dt)
     # budgets = 1.5 x measured on MI355X in round 3 (bf16 0.149 / f16 0.0214 max |dlog-prob| on these 6 crops)
     for dt, tol in (("bf16", 0.23), ("f16", 0.033)):
         err = float((SVTRv2("small", state_dict=sd, dtype=dt)(x.cuda()).cpu() - ref).abs().max())
@@ -118,8 +125,9 @@ def test_ctc_decode_kat_on_device(golden_dir):
     assert out[0] == m.tokenizer.id_to_token[70] * 100 and out[1] == m.tokenizer.id_to_token[71]
 
 
+@pytest.mark.parametrize("dt", PARITY)
 @pytest.mark.parametrize("hw", [(64, 96), (96, 64)])
-def test_dbnet_f32_matches_oracle(hw):
+def test_dbnet_f32_matches_oracle(hw, dt):
     from ocr_vi_invoice_amd import DBNetPP, synth, weights
     from oracle import dbnet_cpu
     sd = weights.make_det_state_dict(seed=21)
@@ -127,7 +135,7 @@ def test_dbnet_f32_matches_oracle(hw):
     imgs = [synth.normalize_chw(synth.make_invoice(s, H, W, lines=3)[0]) for s in (1, 2)]
     x = torch.from_numpy(np.stack(imgs))
     ref = dbnet_cpu.forward(sd, x, return_feats=True)
-    m = DBNetPP(pretrained=False, state_dict=sd, dtype="f32")
+    m = DBNetPP(pretrained=False, state_dict=sd, dtype=dt)
     feats = m.debug_features(x.cuda())
     for k in ("c2", "c3", "c4", "c5", "fused"):
         r = ref[k]
@@ -177,15 +185,16 @@ def test_dbnet_bad_shapes_raise():
         m(torch.zeros(1, 3, 60, 96, device="cuda"))
 
 
+@pytest.mark.parametrize("dt", PARITY)
 @pytest.mark.parametrize("shape", [(1, 16, 8), (3, 32, 100), (2, 48, 36), (1, 64, 320), (5, 16, 512)])
-def test_svtrv2_small_and_ragged_shapes_match_oracle(shape):
+def test_svtrv2_small_and_ragged_shapes_match_oracle(shape, dt):
     """Edge shapes: minimum height 16 (one token row after both merges), widths that give odd / tiny token counts (T = 2, 25, 9),
     the widest sequence the attention kernel holds (64x320 -> 640 / 320 tokens... first global stage 8*80 = 640 > 512 is rejected)."""
     from ocr_vi_invoice_amd import SVTRv2, weights
     from oracle import svtrv2_cpu
     B, H, W = shape
     sd = weights.make_rec_state_dict("tiny", seed=5)
-    m = SVTRv2("tiny", state_dict=sd, dtype="f32")
+    m = SVTRv2("tiny", state_dict=sd, dtype=dt)
     x = torch.randn(B, 3, H, W, generator=torch.Generator().manual_seed(H * W))
     if (H // 8) * (W // 4) > 512:
         with pytest.raises(ValueError, match="512 tokens"):
@@ -199,14 +208,15 @@ def test_svtrv2_small_and_ragged_shapes_match_oracle(shape):
     assert m.decode_probs(lp) == Tokenizer().decode(svtrv2_cpu.greedy_ids(ref))
 
 
+@pytest.mark.parametrize("dt", PARITY)
 @pytest.mark.parametrize("shape", [(1, 32, 32), (3, 32, 64), (1, 160, 96)])
-def test_dbnet_minimum_and_odd_shapes_match_oracle(shape):
+def test_dbnet_minimum_and_odd_shapes_match_oracle(shape, dt):
     from ocr_vi_invoice_amd import DBNetPP, weights
     from oracle import dbnet_cpu
     N, H, W = shape
     sd = weights.make_det_state_dict(seed=9)
     x = torch.randn(N, 3, H, W, generator=torch.Generator().manual_seed(H + W))
     ref = dbnet_cpu.forward(sd, x)
-    out = DBNetPP(pretrained=False, state_dict=sd, dtype="f32")(x.cuda())
+    out = DBNetPP(pretrained=False, state_dict=sd, dtype=dt)(x.cuda())
     for k in ("binary", "thresh", "thresh_binary"):
         np.testing.assert_allclose(out[k].cpu().numpy(), ref[k].numpy(), atol=1e-3, err_msg=k)

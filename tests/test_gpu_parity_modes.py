@@ -33,15 +33,17 @@ def _bench_crops(n_pages, lines=30, seed0=0):
     return preprocess_crops(pages, rects, (48, 320))
 
 
-def test_f32_mode_strings_equal_cpu_oracle_on_bench_crops():
-    """128 of the bench's own crops (4 pages x 32 lines): fp32-mode strings == CPU-oracle strings, log-probs within 1e-3."""
+@pytest.mark.parametrize("dt", ["f32", "f16x2"])
+def test_f32_mode_strings_equal_cpu_oracle_on_bench_crops(dt):
+    """128 of the bench's own crops (4 pages x 32 lines): parity-mode strings == CPU-oracle strings, log-probs within 1e-3 (and within
+    1e-4, the bar round 2's verdict set for calling f16x2 an fp32-equivalent mode; measured 3.6e-5 / 3.1e-5 over 1920 crops)."""
     from ocr_vi_invoice_amd import SVTRv2, weights
     from ocr_vi_invoice_amd.vocab import Tokenizer
     from oracle import svtrv2_cpu
     torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
     sd = weights.make_rec_state_dict("base", seed=1234)
     crops = _bench_crops(4, lines=32)
-    m = SVTRv2("base", state_dict=sd, dtype="f32")
+    m = SVTRv2("base", state_dict=sd, dtype=dt)
     lp = m(crops)
     got = m.decode_probs(lp)
     xc = crops.cpu()
@@ -50,7 +52,7 @@ def test_f32_mode_strings_equal_cpu_oracle_on_bench_crops():
         ref = svtrv2_cpu.forward(sd, xc[i:i + 32], "base")
         want += Tokenizer().decode(svtrv2_cpu.greedy_ids(ref))
         worst = max(worst, float((lp[:, i:i + 32].cpu() - ref).abs().max()))
-    assert worst < 1e-3, worst
+    assert worst < 1e-4, worst
     assert got == want
     assert m.decode_greedy(crops) == want
 
@@ -81,7 +83,7 @@ def test_lowp_error_budget_and_decidable_steps_on_a_full_batch(dt):
     assert all(a == b for a, b, c in zip(t, t32, clean) if c)
 
 
-@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])   # (the 16-bit modes too: every step of these four golden crops has a top-2 margin above their error)
+@pytest.mark.parametrize("dt", ["f32", "f16x2", "f16", "bf16"])   # (the 16-bit modes too: every step of these four golden crops has a top-2 margin above their error)
 @pytest.mark.parametrize("name", ["rec_base_48x320", "rec_tiny_32x256"])
 def test_strings_equal_reference_goldens(golden_dir, name, dt):
     from ocr_vi_invoice_amd import SVTRv2, weights
@@ -91,8 +93,8 @@ def test_strings_equal_reference_goldens(golden_dir, name, dt):
     assert m.decode_greedy(torch.from_numpy(g["x"]).cuda()) == [str(s) for s in g["strings"]]
 
 
-@pytest.mark.parametrize("post", ["host", "device"])   # whole map to the host / device threshold + components, host finish
-def test_bench_pipeline_small_f32_boxes_and_strings_match_the_oracle_chain(post):
+@pytest.mark.parametrize("post,dt", [("host", "f32"), ("device", "f32"), ("host", "f16x2")])   # whole map to the host / device threshold + components, host finish
+def test_bench_pipeline_small_f32_boxes_and_strings_match_the_oracle_chain(post, dt):
     """configs[3] at reduced size through bench.py's own E2E class (fp32 mode): 6 pages 320x480, 5 lines each, detector -> blended map
     -> D2H -> ocrvi_db_boxes_batch -> crop + SVTRv2-base -> strings, pipelined on two streams + a host thread, against the oracle chain
     on the same inputs (oracle detector -> same blend -> oracle post-processing -> rects -> oracle pre-processing -> oracle recogniser);
@@ -108,7 +110,7 @@ def test_bench_pipeline_small_f32_boxes_and_strings_match_the_oracle_chain(post)
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     H, W, B, lines = 320, 480, 6, 5
-    args = argparse.Namespace(dtype="f32", workload="e2e", batch=B, lines=lines, det_chunk=4, rec_batch=16, height=H, width=W,
+    args = argparse.Namespace(dtype=dt, workload="e2e", batch=B, lines=lines, det_chunk=4, rec_batch=16, height=H, width=W,
                               boxes="detected", post_threads=3, no_graph=False, post=post)
     det_sd, rec_sd = weights.make_det_state_dict(seed=1234), weights.make_rec_state_dict("base", seed=1234)
     imgs, gts = [], []

@@ -13,17 +13,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "ocr_vi_invoice_amd", "csrc")
 
 
-def kernel_bodies(asm_text):
+def kernel_bodies(asm_text, prefix="_ZN5ocrvi16gemm_ring_kernel"):
+    """name -> list of (text, inside_inline_asm) for every kernel whose mangled name starts with `prefix`; labels are kept (as
+    '.LBB..:' entries) so that the checks can follow the control flow"""
     lines = asm_text.split("\n")
     out = {}
     for i, l in enumerate(lines):
-        m = re.match(r"(_ZN5ocrvi16gemm_ring_kernel\w+):", l)
+        m = re.match(r"(" + re.escape(prefix) + r"\w*):", l)
         if not m:
             continue
         body, inasm = [], False
         for t in lines[i + 1:]:
             t = t.strip()
             if "s_endpgm" in t:
+                body.append(("s_endpgm", False))
                 break
             if "#ASMSTART" in t:
                 inasm = True
@@ -31,11 +34,51 @@ def kernel_bodies(asm_text):
             if "#ASMEND" in t:
                 inasm = False
                 continue
+            if re.match(r"\.LBB\w+:", t):
+                body.append((t.split(":")[0] + ":", False))
+                continue
             if not t or t.startswith(";") or t.startswith("."):
                 continue
             body.append((t, inasm))
         out[m.group(1)] = body
     return out
+
+
+def touches_before_wait(body, start, dst):
+    """Instructions that read or write a register of `dst` between body[start] and the inline-asm `s_waitcnt vmcnt` that retires the asm
+    load issued just before body[start] -- followed to the END OF THE BASIC BLOCK only (first label or branch): inside a block the text
+    order is the execution order; across blocks it is not (the block layout interleaves paths that the wave-uniform flags of the kernel
+    make mutually exclusive, and a path-insensitive walk reports registers that a different path legitimately reuses).  What this
+    catches is the realistic failure: a register copy or spill the allocator places right behind the load."""
+    hits = []
+    for t, a in body[start:]:
+        if (a and t.startswith("s_waitcnt vmcnt")) or t.endswith(":") or t.startswith("s_cbranch") or t.startswith("s_branch") or t == "s_endpgm":
+            break
+        if not t.startswith("global_load_dwordx4") and regs_of(t) & dst:
+            hits.append(t)
+    return hits
+
+
+ALL_SOURCES = ["conv_bf16.hip", "conv_f16.hip", "conv_f32.hip", "conv_f16x2.hip", "mlp_fused.hip", "attention.hip"]
+_ASM = {}
+
+
+def asm_of(src):
+    """gfx950 assembly of one translation unit (hipcc -S, device only).  The first call compiles ALL_SOURCES in parallel and keeps the
+    text for the life of the process, so that the checks of one test session share one compilation of each file."""
+    if src not in _ASM:
+        from concurrent.futures import ThreadPoolExecutor
+        todo = [f for f in dict.fromkeys([src] + ALL_SOURCES) if f not in _ASM]
+        with tempfile.TemporaryDirectory() as td:
+            def one(f):
+                out = os.path.join(td, f + ".s")
+                subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-S",
+                                "--cuda-device-only", os.path.join(CSRC, f), "-o", out], check=True, capture_output=True)
+                return f, open(out).read()
+            with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
+                for f, txt in ex.map(one, todo):
+                    _ASM[f] = txt
+    return _ASM[src]
 
 
 def regs_of(text):
@@ -46,11 +89,7 @@ def regs_of(text):
 
 
 def check(src):
-    with tempfile.TemporaryDirectory() as td:
-        out = os.path.join(td, "k.s")
-        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-S",
-                        "--cuda-device-only", os.path.join(CSRC, src), "-o", out], check=True, capture_output=True)
-        bodies = kernel_bodies(open(out).read())
+    bodies = kernel_bodies(asm_of(src))
     assert bodies, "no gemm_ring kernels found in " + src
     report = {}
     for name, body in bodies.items():
@@ -62,15 +101,27 @@ def check(src):
                 continue
             loads += 1
             dst = set(range(int(m.group(1)), int(m.group(2)) + 1))
-            for tt, aa in body[i + 1:]:
-                if aa and tt.startswith("s_waitcnt vmcnt"):
-                    break
-                if not tt.startswith("global_load_dwordx4") and regs_of(tt) & dst:
-                    touches.append((t, tt))
+            touches += [(t, tt) for tt in touches_before_wait(body, i + 1, dst)]
         cwaits = [t for t, a in body if not a and t.startswith("s_waitcnt") and "vmcnt" in t]
-        report[name] = dict(instructions=len(body), scratch=scratch, asm_loads=loads, touches=touches, compiler_vmcnt_waits=cwaits,
+        report[name] = dict(instructions=sum(not t.endswith(":") for t, _ in body), scratch=scratch, asm_loads=loads, touches=touches, compiler_vmcnt_waits=cwaits,
                             mfma=sum("v_mfma" in t for t, _ in body))
     return report
+
+
+# Every other MFMA kernel of the library: no scratch instruction at all (a spill inside dcn_pipe / offs_conv / mlp_fused would be an
+# uncounted VMEM operation in a hand-counted vmcnt protocol; anywhere else it is a performance bug).
+OTHER_KERNELS = ["_ZN5ocrvi15dcn_pipe_kernel", "_ZN5ocrvi16offs_conv_kernel", "_ZN5ocrvi16mlp_fused_kernel", "_ZN5ocrvi16conv_gemm_kernel",
+                 "_ZN5ocrvi14gconv32_kernel", "_ZN5ocrvi16attention_kernel", "_ZN5ocrvi18attention16_kernel"]
+
+
+def check_scratch(src):
+    """name -> (scratch instructions, MFMA instructions) for every non-ring MFMA kernel in the translation unit"""
+    txt = asm_of(src)
+    rep = {}
+    for prefix in OTHER_KERNELS:
+        for name, body in kernel_bodies(txt, prefix).items():
+            rep[name] = (sum("scratch_" in t for t, _ in body), sum("v_mfma" in t for t, _ in body))
+    return rep
 
 
 if __name__ == "__main__":
