@@ -7,6 +7,11 @@
 // (IntersectPoint / TopX) -> FixupOutPolygon (duplicate and collinear vertices dropped) -> BuildResult's emission order.
 // What is claimed is the CYCLIC vertex sequence and its orientation; the start vertex follows the rule Clipper's sweep gives for an
 // outline with one top vertex (the top-most vertex -- right-most on a tie -- is emitted last) and is a modelling choice otherwise.
+// MULTI-PATH RESULTS.  When the positive region encloses a pocket (a C-shaped polygon whose mouth is narrower than 2*delta), Clipper returns
+// two paths, outer loop and hole.  The reference wraps them in np.array() inside a try (src/det/test.py:37-43, 84-90): ragged paths raise on
+// numpy >= 1.24 (the box is then skipped) and give an object array on older numpy (element 0 = Clipper's first path).  Neither pyclipper nor
+// the reference's numpy version can be pinned here, so this is a stated modelling choice: the box is KEPT and its polygon is the OUTER loop
+// (tests/test_unclip_union_cpu.py::test_union_with_an_enclosed_pocket_emits_the_outer_loop_only pins product == oracle on such a shape).
 // Host-only code; oracle/dbpost_cpu.py (clipper_union_outline) is the independent Python statement it must agree with exactly.
 #pragma once
 #include <math.h>

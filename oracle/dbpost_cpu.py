@@ -411,7 +411,10 @@ def _clipper_intersect_point(sa, sb):
 
 
 def _fixup_and_emit(outline):
-    """outline: the union's outer loop in emission direction (positive area).  Clipper holds it as a ring whose Next direction is the
+    """(Multi-path results -- a region that encloses a pocket: only the OUTER loop is returned, as the product does; the reference's
+    np.array(Execute(d)) either raises on the ragged list (box skipped) or yields Clipper's first path, depending on its numpy: a stated
+    modelling choice, see csrc/clip_union.h.)
+    outline: the union's outer loop in emission direction (positive area).  Clipper holds it as a ring whose Next direction is the
     reverse, with OutRec.Pts at the top vertex; FixupOutPolygon walks that ring from Pts, and BuildResult emits from Pts->Prev along Prev."""
     m = len(outline)
     if m < 3:

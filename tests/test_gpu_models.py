@@ -166,6 +166,31 @@ def test_dbnet_lowp_error_budget(dt, tol):
     assert err < tol
 
 
+def test_module_surface_nonstrict_loading_and_device_moves():
+    """nn.Module semantics of the facades: load_state_dict(strict=False) keeps the current values of missing tensors (strict=True raises),
+    and .to('cuda') -- the reference's model.to(device) pattern with an index-less device (pipeline2.py:53) -- keeps the handle."""
+    from ocr_vi_invoice_amd import SVTRv2, weights
+    m = SVTRv2("tiny", seed=4, dtype="f32")
+    x = torch.randn(2, 3, 32, 64, generator=torch.Generator().manual_seed(1)).cuda()
+    before = m(x)
+    full = weights.make_rec_state_dict("tiny", seed=5)
+    part = {k: v for k, v in full.items() if k.startswith("head.")}                  # only the CTC head changes
+    with pytest.raises(RuntimeError, match="missing key"):
+        m.load_state_dict(part)                                                      # strict (default): torch raises, so do we
+    m.load_state_dict(part, strict=False)
+    mixed = dict(weights.make_rec_state_dict("tiny", seed=4))
+    mixed.update(part)
+    want = SVTRv2("tiny", state_dict=mixed, dtype="f32")(x)
+    after = m(x)
+    assert torch.equal(after, want) and not torch.equal(after, before)
+    h = m._handle
+    assert m.to("cuda") is m and m._handle is h                                      # same device: nothing is rebuilt
+    assert m.to(torch.device("cuda", torch.cuda.current_device())) is m and m._handle is h
+    with pytest.raises(ValueError):
+        m.to("cpu")
+    assert (m.dtype, SVTRv2("tiny").dtype) == (0, 0)                                 # the default compute mode is the exact-fp32 one
+
+
 def test_batch_limits_are_reported_not_crashed():
     from ocr_vi_invoice_amd import DBNetPP, SVTRv2
     m = DBNetPP(pretrained=False, dtype="bf16")

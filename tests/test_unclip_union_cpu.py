@@ -102,6 +102,27 @@ def test_slit_narrower_than_twice_delta_closes():
     assert (min(xs), max(xs), min(ys), max(ys)) == (-20, 420, -20, 220)
 
 
+def test_union_with_an_enclosed_pocket_emits_the_outer_loop_only():
+    """A C-shaped region whose 10-wide mouth closes under delta = 20: the positive-winding region is then a ring around an enclosed
+    pocket, and Clipper's Execute returns TWO paths (the outer loop and the pocket's hole).  The reference does
+    ``np.array(offset.Execute(distance))`` inside a try (src/det/test.py:37-43, 84-90): with paths of different lengths numpy >= 1.24
+    raises and the reference's except skips the box, older numpy builds an object array whose element 0 is Clipper's first path.  Which
+    of the two the reference's environment does is not knowable here (pyclipper / numpy version unpinned), so this is a stated MODELLING
+    CHOICE, the same in the product (clip_union.h) and in the oracle: the box is kept and its polygon is the OUTER loop.  DB text regions
+    are unclipped from 4-to-~20-vertex approxPolyDP polygons of text blobs; a mouth narrower than twice the unclip distance around a
+    pocket does not occur on them in practice."""
+    poly = [(0, 0), (400, 0), (400, 195), (340, 195), (340, 60), (60, 60), (60, 340), (340, 340), (340, 205), (400, 205), (400, 400), (0, 400)]
+    out = both(poly, 20.0)                                   # product == oracle, vertex for vertex
+    xs, ys = [p[0] for p in out], [p[1] for p in out]
+    assert (min(xs), max(xs), min(ys), max(ys)) == (-20, 420, -20, 420)
+    assert shoelace2(out) > 0                                # Clipper's orientation for an outer path
+    # no vertex of the emitted path lies on the pocket's boundary (the hole path is not spliced in)
+    assert not any(80 - 1 <= x <= 320 + 1 and 80 - 1 <= y <= 320 + 1 for x, y in out)
+    # the mouth is closed: the outline runs straight down the right side at x = 420 past y = 200
+    assert any(x == 420 and y < 190 for x, y in out) and any(x == 420 and y > 210 for x, y in out)
+    assert not any(330 < x < 419 and 190 <= y <= 210 for x, y in out)
+
+
 def test_convex_polygons_keep_the_raw_path():
     """No concave vertex -> no crossing: the union only drops collinear points and re-bases the list (cyclic equality with the raw path)."""
     from scipy.spatial import ConvexHull
