@@ -106,13 +106,20 @@ __global__ __launch_bounds__(NWV * 64) void attention_kernel(const T* __restrict
             }
             const int sw = swz128(lr);
             const int o0 = ((2 * g) ^ sw) << 4, o1 = ((2 * g + 1) ^ sw) << 4;
+            uint4 qs[2] = {qf[0], qf[1]};                       // f16x2: the query fragments half-swapped once per q-tile (no per-key moves)
+            if constexpr (IsSplit<T>::value) { qs[0] = Mma<T>::swapped(qf[0]); qs[1] = Mma<T>::swapped(qf[1]); }
 #pragma unroll
             for (int t = 0; t < MAXT; ++t) {
                 acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 const char* kr = Ksq + (t * 16 + lr) * KROW;
                 const uint4 kf0 = *(const uint4*)(kr + o0), kf1 = *(const uint4*)(kr + o1);
-                Mma<T>::half(kf0, qf[0], acc[t]);
-                Mma<T>::half(kf1, qf[1], acc[t]);
+                if constexpr (IsSplit<T>::value) {
+                    Mma<T>::pair(kf0, qf[0], qs[0], acc[t]);
+                    Mma<T>::pair(kf1, qf[1], qs[1], acc[t]);
+                } else {
+                    Mma<T>::half(kf0, qf[0], acc[t]);
+                    Mma<T>::half(kf1, qf[1], acc[t]);
+                }
             }
         } else {
             uint4 qf = make_uint4(0, 0, 0, 0);
@@ -162,10 +169,11 @@ __global__ __launch_bounds__(NWV * 64) void attention_kernel(const T* __restrict
             for (int t = 0; t < MAXT; ++t) {
                 const float pv[4] = {acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
                 const uint4 pf = Chunk<T>::pack(pv);                   // keys 16 t + 4 g .. + 3 of query lr: [4 hi | 4 lo]
+                const uint4 ps = Mma<T>::swapped(pf);                  // [4 lo | 4 hi]: the swap is on P (once per tile), not on the V fragments
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
                     const uint4 vf = *(const uint4*)(Vtq + (dt * 16 + lr) * VS + (t * 16 + 4 * g) * 4);   // the same keys of head-dim row 16 dt + lr
-                    Mma<T>::half(vf, pf, o[dt]);
+                    Mma<T>::pair(vf, pf, ps, o[dt]);
                 }
             }
         } else if constexpr (sizeof(T) == 4) {

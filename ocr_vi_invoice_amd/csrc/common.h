@@ -109,22 +109,44 @@ template <> struct Chunk<f16_t> {
     }
 };
 
-template <> struct Chunk<f16x2_t> {   // [4 hi | 4 lo]
+// v_fma_mix_f32: an fp32 fma whose operands may be fp16 halves of a register, converted on the fly (hipcc does not select it from C++:
+// it emits a v_cvt_f32_f16 per half first).  d = a * (float)half(b) + c with the LOW / HIGH half of the packed register b.
+__device__ __forceinline__ float fma_mix_lo(float a, unsigned b, float c) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ float fma_mix_hi(float a, unsigned b, float c) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+template <> struct Chunk<f16x2_t> {   // [4 hi | 4 lo]: u.x = (hi0, hi1), u.y = (hi2, hi3), u.z = (lo0, lo1), u.w = (lo2, lo3)
     static constexpr int N = 4;
+    // acc[e] += w * (hi_e + lo_e): eight mixed-precision fmas, the fp16 halves are never converted separately (small term first)
+    __device__ static inline void fma(const uint4& u, float w, float* acc) {
+        acc[0] = fma_mix_lo(w, u.x, fma_mix_lo(w, u.z, acc[0]));
+        acc[1] = fma_mix_hi(w, u.x, fma_mix_hi(w, u.z, acc[1]));
+        acc[2] = fma_mix_lo(w, u.y, fma_mix_lo(w, u.w, acc[2]));
+        acc[3] = fma_mix_hi(w, u.y, fma_mix_hi(w, u.w, acc[3]));
+    }
     __device__ static inline void unpack(const uint4& u, float* f) {
-        union { uint4 u; f16_t h[8]; } r;
-        r.u = u;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) f[i] = (float)r.h[i] + (float)r.h[4 + i];
+        union { uint2 u; f16_t h[4]; } r;
+        r.u = make_uint2(u.x, u.y);
+        f[0] = fma_mix_lo(1.0f, u.z, (float)r.h[0]);
+        f[1] = fma_mix_hi(1.0f, u.z, (float)r.h[1]);
+        f[2] = fma_mix_lo(1.0f, u.w, (float)r.h[2]);
+        f[3] = fma_mix_hi(1.0f, u.w, (float)r.h[3]);
     }
     __device__ static inline uint4 pack(const float* f) {
-        union { f16_t h[8]; uint4 u; } r;
+        union { f16_t h[4]; uint2 u; } hi, lo;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            r.h[i] = (f16_t)f[i];
-            r.h[4 + i] = (f16_t)(f[i] - (float)r.h[i]);
-        }
-        return r.u;
+        for (int i = 0; i < 4; ++i) hi.h[i] = (f16_t)f[i];                       // v_cvt_pk_f16_f32, round to nearest even
+        lo.h[0] = (f16_t)fma_mix_lo(-1.0f, hi.u.x, f[0]);                        // x - hi is exact in fp32
+        lo.h[1] = (f16_t)fma_mix_hi(-1.0f, hi.u.x, f[1]);
+        lo.h[2] = (f16_t)fma_mix_lo(-1.0f, hi.u.y, f[2]);
+        lo.h[3] = (f16_t)fma_mix_hi(-1.0f, hi.u.y, f[3]);
+        return make_uint4(hi.u.x, hi.u.y, lo.u.x, lo.u.y);
     }
 };
 
@@ -216,12 +238,22 @@ template <> struct Mma<f16x2_t> {   // operands are chunks [4 hi | 4 lo]: hh + l
         // (register vectors, not uint4 structs: with the structs hipcc kept fragment arrays in scratch memory to form the swapped operand)
         const u4v av = {a.x, a.y, a.z, a.w}, bv = {b.x, b.y, b.z, b.w};
         const u4v as = __builtin_shufflevector(av, av, 2, 3, 0, 1);
+#ifndef OCRVI_TIMING_HALF_MFMA   /* timing experiment only (results are wrong): what the kernels would cost with half the matrix work */
         c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, as), __builtin_bit_cast(f16x8, bv), c, 0, 0, 0);
+#endif
         c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, bv), c, 0, 0, 0);
     }
     __device__ static inline void run(const uint4 (&a)[2], const uint4 (&b)[2], f32x4& c) {
         half(a[0], b[0], c);
         half(a[1], b[1], c);
+    }
+    // the same with the half-swapped form of `b` supplied by the caller (a register-resident operand that meets many `a` fragments is
+    // swapped once instead of swapping every `a`): a.b = hh + ll, a.swap(b) = hl + lh
+    __device__ static inline uint4 swapped(const uint4& b) { return make_uint4(b.z, b.w, b.x, b.y); }
+    __device__ static inline void pair(const uint4& a, const uint4& b, const uint4& bs, f32x4& c) {
+        const u4v av = {a.x, a.y, a.z, a.w}, bv = {b.x, b.y, b.z, b.w}, sv = {bs.x, bs.y, bs.z, bs.w};
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, sv), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, bv), c, 0, 0, 0);
     }
 };
 

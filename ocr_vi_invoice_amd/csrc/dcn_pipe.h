@@ -147,9 +147,13 @@ __global__ __launch_bounds__(512, 2) void dcn_pipe_kernel(const ConvParams p) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const uint4 u = make_uint4(S.c[it][q].x, S.c[it][q].y, S.c[it][q].z, S.c[it][q].w);
-                    Chunk<T>::unpack(u, f);
+                    if constexpr (IsSplit<T>::value) {
+                        Chunk<T>::fma(u, S.w[it][q], acc);      // both halves of every channel in mixed-precision fmas, no separate conversions
+                    } else {
+                        Chunk<T>::unpack(u, f);
 #pragma unroll
-                    for (int e = 0; e < EPC; ++e) acc[e] = fmaf(S.w[it][q], f[e], acc[e]);
+                        for (int e = 0; e < EPC; ++e) acc[e] = fmaf(S.w[it][q], f[e], acc[e]);
+                    }
                 }
                 const int row = grow + 64 * it;
                 *(uint4*)(slab + row * 128 + ((gj ^ swz128(row)) << 4)) = Chunk<T>::pack(acc);
