@@ -106,17 +106,24 @@ __global__ __launch_bounds__(NWV * 64) void attention_kernel(const T* __restrict
             }
             const int sw = swz128(lr);
             const int o0 = ((2 * g) ^ sw) << 4, o1 = ((2 * g + 1) ^ sw) << 4;
-            uint4 qs[2] = {qf[0], qf[1]};                       // f16x2: the query fragments half-swapped once per q-tile (no per-key moves)
-            if constexpr (IsSplit<T>::value) { qs[0] = Mma<T>::swapped(qf[0]); qs[1] = Mma<T>::swapped(qf[1]); }
+            if constexpr (IsSplit<T>::value) {   // three MFMAs per 16-key tile: (hi, lo) quartets of the 8 head-dim slots of this lane
+                typedef typename Mma<T>::u4v U;
+                U qH, qL;
+                Mma<T>::regroup(qf[0], qf[1], qH, qL);
 #pragma unroll
-            for (int t = 0; t < MAXT; ++t) {
-                acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                const char* kr = Ksq + (t * 16 + lr) * KROW;
-                const uint4 kf0 = *(const uint4*)(kr + o0), kf1 = *(const uint4*)(kr + o1);
-                if constexpr (IsSplit<T>::value) {
-                    Mma<T>::pair(kf0, qf[0], qs[0], acc[t]);
-                    Mma<T>::pair(kf1, qf[1], qs[1], acc[t]);
-                } else {
+                for (int t = 0; t < MAXT; ++t) {
+                    acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    const char* kr = Ksq + (t * 16 + lr) * KROW;
+                    U kH, kL;
+                    Mma<T>::regroup(*(const uint4*)(kr + o0), *(const uint4*)(kr + o1), kH, kL);
+                    Mma<T>::three(kH, kL, qH, qL, acc[t]);
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < MAXT; ++t) {
+                    acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    const char* kr = Ksq + (t * 16 + lr) * KROW;
+                    const uint4 kf0 = *(const uint4*)(kr + o0), kf1 = *(const uint4*)(kr + o1);
                     Mma<T>::half(kf0, qf[0], acc[t]);
                     Mma<T>::half(kf1, qf[1], acc[t]);
                 }
@@ -166,14 +173,24 @@ __global__ __launch_bounds__(NWV * 64) void attention_kernel(const T* __restrict
         f32x4 osum = (f32x4){0.f, 0.f, 0.f, 0.f};  // 16-bit modes: row sums by MFMA against a ones fragment
         if constexpr (IsSplit<T>::value) {
 #pragma unroll
-            for (int t = 0; t < MAXT; ++t) {
-                const float pv[4] = {acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
-                const uint4 pf = Chunk<T>::pack(pv);                   // keys 16 t + 4 g .. + 3 of query lr: [4 hi | 4 lo]
-                const uint4 ps = Mma<T>::swapped(pf);                  // [4 lo | 4 hi]: the swap is on P (once per tile), not on the V fragments
+            for (int s = 0; s < (MAXT + 1) / 2; ++s) {       // 32 keys per step: the P chunks of tiles 2s and 2s + 1 form one (hi, lo) quartet pair
+                typedef typename Mma<T>::u4v U;
+                const float p0[4] = {acc[2 * s][0], acc[2 * s][1], acc[2 * s][2], acc[2 * s][3]};
+                const uint4 c0 = Chunk<T>::pack(p0);                   // keys 32 s + 4 g .. + 3 of query lr: [4 hi | 4 lo]
+                uint4 c1 = make_uint4(0, 0, 0, 0);                     // keys 32 s + 16 + 4 g .. + 3 (nothing past the last tile)
+                if (2 * s + 1 < MAXT) {
+                    const int t1 = 2 * s + 1 < MAXT ? 2 * s + 1 : 0;
+                    const float p1[4] = {acc[t1][0], acc[t1][1], acc[t1][2], acc[t1][3]};
+                    c1 = Chunk<T>::pack(p1);
+                }
+                U pH, pL;
+                Mma<T>::regroup(c0, c1, pH, pL);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
-                    const uint4 vf = *(const uint4*)(Vtq + (dt * 16 + lr) * VS + (t * 16 + 4 * g) * 4);   // the same keys of head-dim row 16 dt + lr
-                    Mma<T>::pair(vf, pf, ps, o[dt]);
+                    const char* vr = Vtq + (dt * 16 + lr) * VS + (32 * s + 4 * g) * 4;   // the same keys of head-dim row 16 dt + lr (staged to whole 32-key steps)
+                    U vH, vL;
+                    Mma<T>::regroup(*(const uint4*)vr, *(const uint4*)(vr + 64), vH, vL);
+                    Mma<T>::three(vH, vL, pH, pL, o[dt]);
                 }
             }
         } else if constexpr (sizeof(T) == 4) {

@@ -247,6 +247,19 @@ template <> struct Mma<f16x2_t> {   // operands are chunks [4 hi | 4 lo]: hh + l
         half(a[0], b[0], c);
         half(a[1], b[1], c);
     }
+    // THREE-PRODUCT FORM.  A lane's operand for one 128-byte K-step is two chunks, c0 = [hi | lo] of k-group 2g and c1 = [hi | lo] of k-group
+    // 2g + 1.  Regrouped in registers into H = (hi of both groups) and L = (lo of both groups) -- a permutation of the lane's 8 k-slots that
+    // is applied to both operands alike -- the product needs only  wL.xH + wH.xL + wH.xH : three MFMAs per 32 k-steps instead of four (the
+    // lo.lo term, 2^-22 of the product at most, is dropped; tools/split_probe.hip prices it).  No memory layout changes.
+    __device__ static inline void regroup(const uint4& c0, const uint4& c1, u4v& H, u4v& L) {
+        H = (u4v){c0.x, c0.y, c1.x, c1.y};
+        L = (u4v){c0.z, c0.w, c1.z, c1.w};
+    }
+    __device__ static inline void three(const u4v& wH, const u4v& wL, const u4v& xH, const u4v& xL, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wL), __builtin_bit_cast(f16x8, xH), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wH), __builtin_bit_cast(f16x8, xL), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wH), __builtin_bit_cast(f16x8, xH), c, 0, 0, 0);
+    }
     // the same with the half-swapped form of `b` supplied by the caller (a register-resident operand that meets many `a` fragments is
     // swapped once instead of swapping every `a`): a.b = hh + ll, a.swap(b) = hl + lh
     __device__ static inline uint4 swapped(const uint4& b) { return make_uint4(b.z, b.w, b.x, b.y); }

@@ -165,6 +165,20 @@ __global__ __launch_bounds__(512, 2) void dcn_pipe_kernel(const ConvParams p) {
         auto mma = [&](int ks) {
             const char* As = Sl + (ks & 1) * SLAB + (wm * 32 + lr) * 128;
             const char* Bs = Wr + (ks % 3) * WST + (wn * (BN / 2) + brow) * 128;
+            if constexpr (IsSplit<T>::value) {   // f16x2: three MFMAs per fragment pair (Mma<f16x2_t>::regroup / three)
+                typedef typename Mma<T>::u4v U;
+                U xH[2], xL[2];
+                Mma<T>::regroup(*(const uint4*)(As + foa0), *(const uint4*)(As + foa1), xH[0], xL[0]);
+                Mma<T>::regroup(*(const uint4*)(As + 16 * 128 + foa0), *(const uint4*)(As + 16 * 128 + foa1), xH[1], xL[1]);
+#pragma unroll
+                for (int a = 0; a < NI; ++a) {
+                    const char* r = Bs + (16 * a) * 128;      // (PERM is false for a 4-byte type)
+                    U wH, wL;
+                    Mma<T>::regroup(*(const uint4*)(r + fob0), *(const uint4*)(r + fob1), wH, wL);
+                    Mma<T>::three(wH, wL, xH[0], xL[0], acc[a][0]);
+                    Mma<T>::three(wH, wL, xH[1], xL[1], acc[a][1]);
+                }
+            } else
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int foa = h == 0 ? foa0 : foa1, fob = h == 0 ? fob0 : fob1;

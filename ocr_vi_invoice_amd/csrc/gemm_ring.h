@@ -450,8 +450,47 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams 
                 issue_piece(IC<4>{}); issue_piece(IC<5>{}); issue_piece(IC<6>{}); issue_piece(IC<7>{});
             }
         }
-        half(IC<0>{});
-        half(IC<1>{});
+        if constexpr (IsSplit<T>::value) {
+            // f16x2: both chunks of every fragment at once, regrouped into (hi, lo) quartets: three MFMAs per fragment pair (Mma<f16x2_t>)
+            typedef typename Mma<T>::u4v U;
+            // (row blocks in groups of XB: with all MI = 4 blocks' fragments live next to two accumulator sets the 256-row build spills; the
+            // weight fragments are then read from LDS once per group, i.e. twice)
+            constexpr int XB = MI >= 4 ? 2 : MI;
+            auto srow = [&](auto A, auto B0, const U (&xH)[XB], const U (&xL)[XB]) {
+                constexpr int a = decltype(A)::value, b0 = decltype(B0)::value;
+                const char* r = Bs + (wn * TN + a_row(a) + brow) * 128;
+                U wH, wL;
+                Mma<T>::regroup(*(const uint4*)(r + fob0), *(const uint4*)(r + fob1), wH, wL);
+#pragma unroll
+                for (int b = 0; b < XB; ++b) Mma<T>::three(wH, wL, xH[b], xL[b], acc[a][b0 + b]);
+                if constexpr (SPREAD && b0 == 0) {   // pieces 2a, 2a + 1 of stage s + 2 ride in the shadow of this row's MFMAs
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (dma) {
+                        issue_piece(IC<2 * a>{});
+                        issue_piece(IC<2 * a + 1>{});
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            auto sgroup = [&](auto B0) {
+                constexpr int b0 = decltype(B0)::value;
+                U xH[XB], xL[XB];
+#pragma unroll
+                for (int b = 0; b < XB; ++b) {
+                    const char* r = As + (wm * TM + (b0 + b) * 16 + lr) * 128;
+                    Mma<T>::regroup(*(const uint4*)(r + foa0), *(const uint4*)(r + foa1), xH[b], xL[b]);
+                }
+                srow(IC<0>{}, B0, xH, xL); srow(IC<1>{}, B0, xH, xL); srow(IC<2>{}, B0, xH, xL); srow(IC<3>{}, B0, xH, xL);
+            };
+            sgroup(IC<0>{});
+            if constexpr (MI > XB) {
+                __builtin_amdgcn_sched_barrier(0);
+                sgroup(IC<XB>{});
+            }
+        } else {
+            half(IC<0>{});
+            half(IC<1>{});
+        }
         if (dma) end_issue();
         tick(2);
         if constexpr (grp >= 0) {

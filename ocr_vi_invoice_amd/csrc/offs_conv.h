@@ -109,6 +109,25 @@ __global__ __launch_bounds__(512, 1) void offs_conv_kernel(const ConvParams p, i
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3, dx = tap - dy * 3;
+            if constexpr (IsSplit<T>::value) {   // f16x2: three MFMAs per fragment pair (Mma<f16x2_t>::regroup / three)
+                typedef typename Mma<T>::u4v U;
+                U xH[MBW], xL[MBW];
+#pragma unroll
+                for (int b = 0; b < MBW; ++b) {
+                    const int pp = ((mb0 + b) * S + dy) * PW + lr * S + dx;
+                    const char* r = Ps + pp * 128;
+                    Mma<T>::regroup(*(const uint4*)(r + (((2 * g) ^ swz128(pp)) << 4)), *(const uint4*)(r + (((2 * g + 1) ^ swz128(pp)) << 4)), xH[b], xL[b]);
+                }
+#pragma unroll
+                for (int a = 0; a < NBW; ++a) {
+                    const int n = (nb0 + a) * 16 + lr;
+                    const char* r = Ws + (tap * 32 + n) * 128;
+                    U wH, wL;
+                    Mma<T>::regroup(*(const uint4*)(r + (((2 * g) ^ swz128(n)) << 4)), *(const uint4*)(r + (((2 * g + 1) ^ swz128(n)) << 4)), wH, wL);
+#pragma unroll
+                    for (int b = 0; b < MBW; ++b) Mma<T>::three(wH, wL, xH[b], xL[b], acc[a][b]);
+                }
+            } else
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 uint4 wf[NBW], xf[MBW];
