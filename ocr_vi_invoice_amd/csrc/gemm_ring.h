@@ -456,31 +456,40 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams 
             // (row blocks in groups of XB: with all MI = 4 blocks' fragments live next to two accumulator sets the 256-row build spills; the
             // weight fragments are then read from LDS once per group, i.e. twice)
             constexpr int XB = MI >= 4 ? 2 : MI;
-            auto srow = [&](auto A, auto B0, const U (&xH)[XB], const U (&xL)[XB]) {
-                constexpr int a = decltype(A)::value, b0 = decltype(B0)::value;
+            // weight fragments are fetched one row AHEAD of the MFMAs that use them (raw chunks: 8 registers), so that a row's LDS latency and
+            // regrouping moves fall under the previous row's MFMAs instead of in front of its own
+            auto wread = [&](int a, uint4& c0, uint4& c1) {
                 const char* r = Bs + (wn * TN + a_row(a) + brow) * 128;
-                U wH, wL;
-                Mma<T>::regroup(*(const uint4*)(r + fob0), *(const uint4*)(r + fob1), wH, wL);
-#pragma unroll
-                for (int b = 0; b < XB; ++b) Mma<T>::three(wH, wL, xH[b], xL[b], acc[a][b0 + b]);
-                if constexpr (SPREAD && b0 == 0) {   // pieces 2a, 2a + 1 of stage s + 2 ride in the shadow of this row's MFMAs
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (dma) {
-                        issue_piece(IC<2 * a>{});
-                        issue_piece(IC<2 * a + 1>{});
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                c0 = *(const uint4*)(r + fob0);
+                c1 = *(const uint4*)(r + fob1);
             };
             auto sgroup = [&](auto B0) {
                 constexpr int b0 = decltype(B0)::value;
+                uint4 n0, n1;
+                wread(0, n0, n1);
                 U xH[XB], xL[XB];
 #pragma unroll
                 for (int b = 0; b < XB; ++b) {
                     const char* r = As + (wm * TM + (b0 + b) * 16 + lr) * 128;
                     Mma<T>::regroup(*(const uint4*)(r + foa0), *(const uint4*)(r + foa1), xH[b], xL[b]);
                 }
-                srow(IC<0>{}, B0, xH, xL); srow(IC<1>{}, B0, xH, xL); srow(IC<2>{}, B0, xH, xL); srow(IC<3>{}, B0, xH, xL);
+                auto srow = [&](auto A) {
+                    constexpr int a = decltype(A)::value;
+                    U wH, wL;
+                    Mma<T>::regroup(n0, n1, wH, wL);
+                    if constexpr (a + 1 < NI) wread(a + 1, n0, n1);
+#pragma unroll
+                    for (int b = 0; b < XB; ++b) Mma<T>::three(wH, wL, xH[b], xL[b], acc[a][b0 + b]);
+                    if constexpr (SPREAD && b0 == 0) {   // pieces 2a, 2a + 1 of stage s + 2 ride in the shadow of this row's MFMAs
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (dma) {
+                            issue_piece(IC<2 * a>{});
+                            issue_piece(IC<2 * a + 1>{});
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                };
+                srow(IC<0>{}); srow(IC<1>{}); srow(IC<2>{}); srow(IC<3>{});
             };
             sgroup(IC<0>{});
             if constexpr (MI > XB) {

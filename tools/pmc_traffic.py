@@ -21,36 +21,36 @@ def collect(d, counter):
 
 
 AMODE = {"0": "conv1x1", "1": "conv3x3", "2": "stem_conv", "3": "dcn3x3"}
-DT = {"DF16b": "bf16", "DF16_": "f16", "f": "f32"}
+DT = {"DF16b": "bf16", "DF16_": "f16", "f": "f32", "NS_7f16x2_tE": "f16x2"}
 
 
-DEM = {"float": "f32", "__bf16": "bf16", "_Float16": "f16"}
+DEM = {"float": "f32", "__bf16": "bf16", "_Float16": "f16", "ocrvi::f16x2_t": "f16x2"}
 
 
 def tag_of(name):
     """Kernel name (mangled or demangled, as rocprofv3 prints it) -> the tag bench.py's profiler uses for that kernel."""
-    m = re.search(r"gemm_ring_kernel<(float|__bf16|_Float16)", name)
+    m = re.search(r"gemm_ring_kernel<(float|__bf16|_Float16|ocrvi::f16x2_t)", name)
     if m:
         return "gemm_ring_" + DEM[m.group(1)]
-    m = re.search(r"conv_gemm_kernel<(float|__bf16|_Float16), (\d), (\d+), (\d+)", name)
+    m = re.search(r"conv_gemm_kernel<(float|__bf16|_Float16|ocrvi::f16x2_t), (\d), (\d+), (\d+)", name)
     if m:
         return f"{AMODE.get(m.group(2), 'conv')}_{m.group(3)}x{m.group(4)}_{DEM[m.group(1)]}"
-    m = re.search(r"attention(16)?_kernel<(float|__bf16|_Float16)", name)
+    m = re.search(r"attention(16)?_kernel<(float|__bf16|_Float16|ocrvi::f16x2_t)", name)
     if m:
         return "attention_hd32_" + DEM[m.group(2)]
-    m = re.search(r"gemm_ring_kernelI(DF16b|DF16_|f)", name)
+    m = re.search(r"gemm_ring_kernelI(DF16b|DF16_|f|NS_7f16x2_tE)", name)
     if m:
         return "gemm_ring_" + DT.get(m.group(1), m.group(1))
-    m = re.search(r"conv_gemm_kernelI(DF16b|DF16_|f)Li(\d)ELi(\d+)ELi(\d+)E", name)
+    m = re.search(r"conv_gemm_kernelI(DF16b|DF16_|f|NS_7f16x2_tE)Li(\d)ELi(\d+)ELi(\d+)E", name)
     if m:
         return f"{AMODE.get(m.group(2), 'conv')}_{m.group(3)}x{m.group(4)}_{DT[m.group(1)]}"
     m = re.search(r"mlp_fused_kernelI(DF16b|DF16_)Li(\d+)E", name)
     if m:
         return f"mlp_fused_d{m.group(2)}_{DT[m.group(1)]}"
-    m = re.search(r"dcn_pipe_kernelI(DF16b|DF16_)Li(\d+)E", name)
+    m = re.search(r"dcn_pipe_kernelI(DF16b|DF16_|f|NS_7f16x2_tE)Li(\d+)E", name)
     if m:
         return f"dcn3x3_pipe128x{m.group(2)}_{DT[m.group(1)]}"
-    m = re.search(r"attention(16)?_kernelI(DF16b|DF16_|f)", name)
+    m = re.search(r"attention(16)?_kernelI(DF16b|DF16_|f|NS_7f16x2_tE)", name)
     if m:
         return "attention_hd32_" + DT[m.group(2)]
     m = re.search(r"gconv32_kernelI(DF16b|DF16_)", name)
@@ -79,7 +79,7 @@ if __name__ == "__main__":
                       "write_bytes_per_launch": round(a["write"] / a["dispatches"]),
                       "traffic_bytes_per_launch": round((a["fetch"] + a["write"]) / a["dispatches"])}
     json.dump({"_method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes (with --kernel-trace only) over `python3 bench.py "
-                          "--steps 1 --warmup 1 --no-graph --no-prof --no-cpu-baseline --no-parity-check` (both modes of the default run); per-launch averages over all dispatches of the kernels that share a "
+                          "--steps 1 --warmup 1 --no-graph --no-prof --no-cpu-baseline --no-parity-check` (every mode of the default run); per-launch averages over all dispatches of the kernels that share a "
                           "tag; bytes = FETCH_SIZE*1024*2 (gfx950 counts 64 B per 128-B request on wide coalesced reads: MI355X_MICROARCH.md, HBM) + "
                           "WRITE_SIZE*1024.  Infinity-Cache hits are included in these fabric-side counters.  Made by tools/pmc_traffic.py.",
                "kernels": kernels}, open(out, "w"), indent=1)

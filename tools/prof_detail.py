@@ -16,7 +16,7 @@ for which, fn in (("det", lambda: det(x)), ("rec", lambda: rec.decode_greedy(c))
     rep = _lib.prof_report()
     tot = sum(v["ms"] for v in rep.values()) / 3
     print(f"== {which} {dt}: {tot:.2f} ms per forward")
-    peak = {"f32": 157.3e12, "f16x2": 625e12}.get(dt, 2500e12)   # f16x2: four 16-bit partial products per product
+    peak = {"f32": 157.3e12, "f16x2": 2500e12 / 3}.get(dt, 2500e12)   # f16x2: three 16-bit partial products per product
     for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"])[:45]:
         ms = v["ms"] / v["launches"]; n = v["launches"] // 3
         tf = v["flops"] / v["launches"] / ms / 1e9; gb = v["bytes"] / v["launches"] / ms / 1e6
