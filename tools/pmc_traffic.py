@@ -38,6 +38,21 @@ def tag_of(name):
     m = re.search(r"attention(16)?_kernel<(float|__bf16|_Float16|ocrvi::f16x2_t)", name)
     if m:
         return "attention_hd32_" + DEM[m.group(2)]
+    m = re.search(r"dcn_pipe_kernel<(float|__bf16|_Float16|ocrvi::f16x2_t), (\d+)>", name)
+    if m:
+        return f"dcn3x3_pipe128x{m.group(2)}_{DEM[m.group(1)]}"
+    m = re.search(r"offs_conv_kernel<(float|__bf16|_Float16|ocrvi::f16x2_t)", name)
+    if m:
+        return "dcn_offset_conv3x3_128x32_" + DEM[m.group(1)]
+    m = re.search(r"offs_conv_kernelI(DF16b|DF16_|f|NS_7f16x2_tE)", name)
+    if m:
+        return "dcn_offset_conv3x3_128x32_" + DT[m.group(1)]
+    m = re.search(r"mlp_fused_kernel<(__bf16|_Float16), (\d+)", name)
+    if m:
+        return f"mlp_fused_d{m.group(2)}_{DEM[m.group(1)]}"
+    m = re.search(r"gconv32_kernel<(__bf16|_Float16)", name)
+    if m:
+        return "gconv3x3_128x32_" + DEM[m.group(1)]
     m = re.search(r"gemm_ring_kernelI(DF16b|DF16_|f|NS_7f16x2_tE)", name)
     if m:
         return "gemm_ring_" + DT.get(m.group(1), m.group(1))
