@@ -210,6 +210,10 @@ int ocrvi_test_attention(int device, int dtype, const float* qkv, int B, int N, 
 int ocrvi_test_mlp(int device, int dtype, float* x, const float* ln_g_host, const float* ln_b_host, const float* w1_host, const float* b1_host,
                    const float* w2_host, const float* b2_host, const float* next_g_host, const float* next_b_host, int want_xn, int M, int D,
                    float* xn_out, int iters, float* avg_ms);
+/* Host-only (no GPU): the OCRVI_F16X2 weight format.  src: n fp32 values of one layer (n % 4 == 0) -> dst: n 4-byte elements, per chunk of
+ * 4 consecutive elements [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3] (fp16), hi + lo = src * 2^s with one power of two s per layer that puts the
+ * largest magnitude into [2^13, 2^14); *wscale = 2^-s.  (What ocrvi_*_create does to every GEMM weight in that mode.) */
+int ocrvi_test_pack_f16x2(const float* src, size_t n, void* dst, float* wscale);
 
 /* Per-launch HIP-event profiler (process-global, off by default).  While enabled every MFMA / bandwidth kernel launch
  * of the graphs above is bracketed by two events recorded on its launch stream.  ocrvi_prof_report synchronises those

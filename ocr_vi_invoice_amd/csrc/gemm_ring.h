@@ -341,7 +341,11 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams 
                     }
                     if (!p.res_post) activate(v);
                     const int c = ch_of(a);
+#ifdef OCRVI_TIMING_RING_OOB_STORES   /* timing experiment only: every store instruction issues but the range check drops all of its lanes */
+                    const unsigned off = OOB;
+#else
                     const unsigned off = (row_b != OOB && nb + c < p.N_g) ? row_b + (unsigned)c * 4u : OOB;
+#endif
                     u32x4 pk;
                     if (IsSplit<T>::value && !p.out_f32) {
                         const uint4 e = Chunk<T>::pack(v);

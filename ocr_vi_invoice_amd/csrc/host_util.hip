@@ -387,5 +387,17 @@ extern "C" int ocrvi_prof_report(char* buf, size_t cap) {
     return OCRVI_OK;
 }
 
+// Test hook (host only, no GPU): the f16x2 weight packer's element format and power-of-two scale.  src [n] fp32 (n % 4 == 0) -> dst [n]
+// 4-byte elements in chunks of [4 hi | 4 lo]; *wscale = what the kernels' epilogues multiply the accumulator by (1 / the storage scale).
+extern "C" int ocrvi_test_pack_f16x2(const float* src, size_t n, void* dst, float* wscale) {
+    using namespace ocrvi;
+    OCRVI_CHECK(src && dst && wscale && n % 4 == 0, OCRVI_EINVAL, "test_pack_f16x2: bad argument");
+    std::vector<float> wt(src, src + n);
+    PackedConv pc = finish_pack(wt, 1, 1, (int)n, OCRVI_F16X2);
+    memcpy(dst, pc.bytes.data(), pc.bytes.size());
+    *wscale = pc.wscale;
+    return OCRVI_OK;
+}
+
 extern "C" const char* ocrvi_last_error(void) { return ocrvi::last_error_cstr(); }
 extern "C" int ocrvi_abi_version(void) { return 1; }

@@ -143,3 +143,34 @@ def test_db_boxes_batch_equals_the_per_page_python_chain():
         assert counts.tolist() == wcounts and counts[2] == 0
         assert np.array_equal(rects, np.asarray(want, np.int32).reshape(-1, 5))
         assert len(scores) == len(rects) and (scores >= 0.5).all()
+
+
+def test_f16x2_weight_format_and_scale():
+    """The fp32-equivalent operand format of dtype f16x2 (include/ocrvi.h): two fp16 halves per element, chunks of [4 hi | 4 lo], one
+    power-of-two scale per layer; host packer against a numpy restatement, and the precision the format promises."""
+    import ctypes as C
+    from ocr_vi_invoice_amd import _lib as L
+    lib = L.load()
+    assert L.dtype_code("f16x2") == 3 and L.dtype_code("f32") == 0
+    rng = np.random.default_rng(7)
+    w = (rng.standard_normal(4096) * 0.03).astype(np.float32)
+    w[5] = 0.0
+    w[6] = 1e-7                                        # far below the largest weight: lands on fp16's subnormal grid, absolute error only
+    dst = np.zeros(4096 * 2, np.float16)
+    ws = C.c_float(0)
+    L.check(lib.ocrvi_test_pack_f16x2(w.ctypes.data, w.size, dst.ctypes.data, C.byref(ws)))
+    scale = 1.0 / ws.value
+    mx = float(np.abs(w).max())
+    assert scale == 2.0 ** round(np.log2(scale)) and 2.0 ** 13 <= mx * scale < 2.0 ** 14
+    x = w.astype(np.float32) * np.float32(scale)
+    hi = x.astype(np.float16)
+    lo = (x - hi.astype(np.float32)).astype(np.float16)
+    want = np.concatenate([hi.reshape(-1, 4), lo.reshape(-1, 4)], 1).reshape(-1)
+    assert np.array_equal(dst.view(np.uint16), want.view(np.uint16))
+    rec = (dst.reshape(-1, 8)[:, :4].astype(np.float64) + dst.reshape(-1, 8)[:, 4:].astype(np.float64)).reshape(-1) / scale
+    err = np.abs(rec - w.astype(np.float64))
+    big = np.abs(w) * scale >= 0.125                   # lo is a normal fp16 number: 2^-23 relative
+    assert np.all(err[big] <= np.abs(w[big]) * 2.0 ** -23 * 1.0001)
+    assert np.all(err[~big] <= 2.0 ** -25 / scale * 1.0001)
+    with pytest.raises(ValueError):
+        L.check(lib.ocrvi_test_pack_f16x2(w.ctypes.data, 6, dst.ctypes.data, C.byref(ws)))
