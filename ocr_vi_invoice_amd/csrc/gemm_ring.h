@@ -203,11 +203,13 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams 
                 const char* src = ((a_mask[pi] >> st_tap) & 1u) ? a_ptr[pi] + st_delta : st_zero;
                 glds16v(src, __builtin_amdgcn_readfirstlane(st_base + (pi * NW + wave) * 1024));
             } else {
-                glds16(st_ak, a_off[pi], __builtin_amdgcn_readfirstlane(st_base + (pi * NW + wave) * 1024));
+                glds16(uniform_ptr(st_ak), a_off[pi], __builtin_amdgcn_readfirstlane(st_base + (pi * NW + wave) * 1024));
             }
         } else if constexpr (pi < G) {
             constexpr int i = pi - NA;
-            glds16(st_bk + (size_t)(i * NW * 8) * ldw_b, b_off, __builtin_amdgcn_readfirstlane(st_base + BM * 128 + (i * NW + wave) * 1024));
+            // (uniform_ptr at the point of use: in one build hipcc otherwise carried the stage base in VGPRs across the specialised epilogue
+            // bodies and could not form the asm statement's SGPR operand)
+            glds16(uniform_ptr(st_bk + (size_t)(i * NW * 8) * ldw_b), b_off, __builtin_amdgcn_readfirstlane(st_base + BM * 128 + (i * NW + wave) * 1024));
         }
     };
     auto end_issue = [&]() {
@@ -305,8 +307,18 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams 
     };
     // bias / activation / residual / store of slice group GRP of the parked tile (accumulators pnd, row tile pmt).  Exactly S32 / S16
     // store instructions per wave: out-of-range lanes write to the dump page instead of being skipped.
-    auto run_group = [&](auto GRP, Acc& pnd, int pmt) {
+    // The wave-uniform flags of the epilogue (residual? in which format? before or after the activation? output format?) are resolved ONCE per
+    // slice group: run_group picks one of the specialised bodies below, inside which nothing branches (as run-time tests per fragment they
+    // were ~10 scalar branches around ~30 vector instructions).
+    const bool out_raw32 = !IsSplit<T>::value || p.out_f32;
+    const int res_kind = !has_res ? 0 : ((IsSplit<T>::value && F32O && !p.res_f32) ? 2 : 1);
+    auto group_body = [&](auto GRP, Acc& pnd, int pmt, auto RES, auto POST, auto OUTF32) {
         constexpr int q0 = decltype(GRP)::value * SPS;
+        // (a negative template value = "read the flag at run time": the 16-bit-output builds keep the run-time form, their GELU variants
+        // have no registers to spare for several specialised bodies)
+        const int RESK = decltype(RES)::value >= 0 ? decltype(RES)::value : res_kind;   // 0 none, 1 raw fp32 (or T for the 16-bit builds), 2 f16x2 chunks
+        const bool post = decltype(POST)::value >= 0 ? decltype(POST)::value != 0 : p.res_post != 0;   // activation before the residual add
+        const bool outf32 = decltype(OUTF32)::value != 0;
         // the bias of the wave's four fragments: all LDS reads in flight together, one wait (the operand fragments are dead here, so the
         // sixteen registers are free)
         float4 bv[NI];
@@ -317,7 +329,7 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams 
         auto frag = [&](float (&v)[4], const f32x4& c, int a) {
             v[0] = unscale<T>(c[0], p.wscale) + bv[a].x; v[1] = unscale<T>(c[1], p.wscale) + bv[a].y;
             v[2] = unscale<T>(c[2], p.wscale) + bv[a].z; v[3] = unscale<T>(c[3], p.wscale) + bv[a].w;
-            if (p.res_post) activate(v);
+            if (post) activate(v);
         };
 #pragma unroll
         for (int j = 0; j < SPS; ++j) {
@@ -328,18 +340,17 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams 
                 for (int a = 0; a < NI; ++a) {
                     float v[4];
                     frag(v, pnd[a][q0 + j], a);
-                    if (has_res) {
+                    if (IsSplit<T>::value && RESK == 2) {   // a residual in the operand format: [4 hi | 4 lo]
                         const u32x4 u = res_r[j][a];
-                        if (IsSplit<T>::value && !p.res_f32) {   // a residual in the operand format: [4 hi | 4 lo]
-                            float rv[4];
-                            Chunk<T>::unpack(make_uint4(u.x, u.y, u.z, u.w), rv);
-                            v[0] += rv[0]; v[1] += rv[1]; v[2] += rv[2]; v[3] += rv[3];
-                        } else {
-                            v[0] += __uint_as_float(u.x); v[1] += __uint_as_float(u.y);
-                            v[2] += __uint_as_float(u.z); v[3] += __uint_as_float(u.w);
-                        }
+                        float rv[4];
+                        Chunk<T>::unpack(make_uint4(u.x, u.y, u.z, u.w), rv);
+                        v[0] += rv[0]; v[1] += rv[1]; v[2] += rv[2]; v[3] += rv[3];
+                    } else if (RESK == 1) {
+                        const u32x4 u = res_r[j][a];
+                        v[0] += __uint_as_float(u.x); v[1] += __uint_as_float(u.y);
+                        v[2] += __uint_as_float(u.z); v[3] += __uint_as_float(u.w);
                     }
-                    if (!p.res_post) activate(v);
+                    if (!post) activate(v);
                     const int c = ch_of(a);
 #ifdef OCRVI_TIMING_RING_OOB_STORES   /* timing experiment only: every store instruction issues but the range check drops all of its lanes */
                     const unsigned off = OOB;
@@ -347,7 +358,7 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams 
                     const unsigned off = (row_b != OOB && nb + c < p.N_g) ? row_b + (unsigned)c * 4u : OOB;
 #endif
                     u32x4 pk;
-                    if (IsSplit<T>::value && !p.out_f32) {
+                    if (IsSplit<T>::value && !outf32) {
                         const uint4 e = Chunk<T>::pack(v);
                         pk = (u32x4){e.x, e.y, e.z, e.w};
                     } else {
@@ -362,7 +373,7 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams 
                     float v0[4], v1[4];
                     frag(v0, pnd[2 * h][q0 + j], 2 * h);
                     frag(v1, pnd[2 * h + 1][q0 + j], 2 * h + 1);
-                    if (has_res) {
+                    if (RESK != 0) {
                         union { u32x4 u; T e[8]; } rr;
                         rr.u = res_r[j][h];
 #pragma unroll
@@ -371,7 +382,7 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams 
                             v1[r] += to_f32<T>(rr.e[4 + r]);
                         }
                     }
-                    if (!p.res_post) {
+                    if (!post) {
                         activate(v0);
                         activate(v1);
                     }
@@ -385,6 +396,35 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams 
                     const unsigned off = (row_b != OOB && nb + c < p.N_g) ? row_b + (unsigned)c * 2u : OOB;
                     __builtin_amdgcn_raw_buffer_store_b128(pk.u, orsrc, off, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    };
+    // (F32O builds of the 16-bit types and of fp32 write raw fp32; only f16x2 has a second 4-byte output format)
+    auto run_group = [&](auto GRP, Acc& pnd, int pmt) {
+        constexpr bool SPEC = F32O && !(IsSplit<T>::value && BM < 256);
+        if constexpr (!SPEC) {
+            // 16-bit output, and the 128-row f16x2 build: flags at run time (see group_body)
+            if constexpr (IsSplit<T>::value) {
+                if (out_raw32) group_body(GRP, pnd, pmt, IC<-1>{}, IC<-1>{}, IC<1>{}); else group_body(GRP, pnd, pmt, IC<-1>{}, IC<-1>{}, IC<0>{});
+            } else {
+                group_body(GRP, pnd, pmt, IC<-1>{}, IC<-1>{}, IC<1>{});
+            }
+        } else {
+            auto with_out = [&](auto RES, auto POST) {
+                if constexpr (IsSplit<T>::value) {
+                    if (out_raw32) group_body(GRP, pnd, pmt, RES, POST, IC<1>{}); else group_body(GRP, pnd, pmt, RES, POST, IC<0>{});
+                } else {
+                    group_body(GRP, pnd, pmt, RES, POST, IC<1>{});
+                }
+            };
+            if (res_kind == 0) {
+                with_out(IC<0>{}, IC<0>{});                       // (without a residual the order of the activation is moot)
+            } else if (res_kind == 1) {
+                if (p.res_post) with_out(IC<1>{}, IC<1>{}); else with_out(IC<1>{}, IC<0>{});
+            } else {
+                if constexpr (IsSplit<T>::value) {
+                    if (p.res_post) with_out(IC<2>{}, IC<1>{}); else with_out(IC<2>{}, IC<0>{});
                 }
             }
         }
