@@ -27,7 +27,7 @@ static int launch_tile(const ConvParams& p, hipStream_t stream) {
 
 template <typename T, int BM, int NW, int SPS, bool F32O, bool C3, int BN, int ACT>
 static int launch_ring_act(const ConvParams& p, int grid, hipStream_t stream) {
-    constexpr int smem = 3 * (BM + BN) * 128 + 512;  // ring + bias
+    constexpr int smem = (NW == 4 ? 2 : 3) * (BM + BN) * 128 + 512;  // ring + bias
     auto kern = gemm_ring_kernel<T, BM, NW, SPS, F32O, C3, BN, false, ACT>;
     OCRVI_TRY(ensure_max_smem((const void*)kern, smem));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), smem, stream, p);
@@ -37,7 +37,7 @@ static int launch_ring_act(const ConvParams& p, int grid, hipStream_t stream) {
 
 template <typename T, int BM, int NW, int SPS, bool F32O, bool C3, int BN = 128>
 static int launch_ring_f(const ConvParams& p, int grid, hipStream_t stream) {
-    constexpr int smem = 3 * (BM + BN) * 128 + 512;  // ring + bias
+    constexpr int smem = (NW == 4 ? 2 : 3) * (BM + BN) * 128 + 512;  // ring + bias
 #ifdef OCRVI_RING_PROF_BUILD
     static const bool prof = getenv("OCRVI_RING_PROF") && atoi(getenv("OCRVI_RING_PROF"));
     if (prof) {  // development aid: cycle breakdown per phase, printed per launch (synchronises)
@@ -51,13 +51,13 @@ static int launch_ring_f(const ConvParams& p, int grid, hipStream_t stream) {
         ConvParams q = p;
         q.out2 = dbuf;
         hipLaunchKernelGGL(pk, dim3(grid), dim3(NW * 64), smem, stream, q);
-        unsigned long long h[4];
-        OCRVI_HIP(hipMemcpyAsync(h, dbuf, 32, hipMemcpyDeviceToHost, stream));
+        unsigned long long h[5];
+        OCRVI_HIP(hipMemcpyAsync(h, dbuf, 40, hipMemcpyDeviceToHost, stream));
         OCRVI_HIP(hipStreamSynchronize(stream));
-        const double w = (double)NW * grid, tot = (double)(h[0] + h[1] + h[2] + h[3]);
-        fprintf(stderr, "ring BM%d NW%d SPS%d M%d N%d K%d grid %d nk %d act %d res %d f32o %d: cycles/wave wait %.0f issue %.0f mma %.0f epi %.0f (%.0f%% %.0f%% %.0f%% %.0f%%)\n",
-                BM, NW, SPS, p.M, p.N_g, p.Kp, grid, p.Kp / (int)(128 / sizeof(T)), p.act, p.res_mode, p.out_f32, h[0] / w, h[1] / w, h[2] / w, h[3] / w,
-                100 * h[0] / tot, 100 * h[1] / tot, 100 * h[2] / tot, 100 * h[3] / tot);
+        const double w = (double)NW * grid, tot = (double)(h[0] + h[1] + h[2] + h[3] + h[4]);
+        fprintf(stderr, "ring BM%d NW%d SPS%d M%d N%d K%d grid %d nk %d act %d res %d f32o %d: cycles/wave own-DMA wait %.0f barrier %.0f issue %.0f mma %.0f epi %.0f (%.0f%% %.0f%% %.0f%% %.0f%% %.0f%%)\n",
+                BM, NW, SPS, p.M, p.N_g, p.Kp, grid, p.Kp / (int)(128 / sizeof(T)), p.act, p.res_mode, p.out_f32, h[4] / w, h[0] / w, h[1] / w, h[2] / w, h[3] / w,
+                100 * h[4] / tot, 100 * h[0] / tot, 100 * h[1] / tot, 100 * h[2] / tot, 100 * h[3] / tot);
         return OCRVI_OK;
     }
 #endif

@@ -67,6 +67,16 @@ __device__ __forceinline__ void gload16s(u32x4& dst, const char* sbase, unsigned
 }
 template <int N> __device__ __forceinline__ void wait_vm_only() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void bind16(u32x4& r) { asm volatile("" : "+v"(r)); }  // every later use of r is ordered after this point
+// (development: -DOCRVI_TIMING_RING_NOLDS replaces the fragment reads of the f16x2 ring by undefined registers -- wrong results, timing only)
+__device__ __forceinline__ uint4 lds16(const char* p) {
+#ifdef OCRVI_TIMING_RING_NOLDS
+    u32x4 v;
+    asm volatile("" : "=v"(v));
+    return make_uint4(v.x, v.y, v.z, v.w);
+#else
+    return *(const uint4*)p;
+#endif
+}
 
 // Epilogue layout.  fp32 output: MFMA block a is channels 16a .. 16a+15, lane (lr, g) holds 4 consecutive ones -> a 16-byte access
 // per lane, 64 contiguous bytes per pixel row per instruction.  16-bit output: the weight fragment of block a reads tile row
@@ -88,11 +98,14 @@ __device__ __forceinline__ void bind16(u32x4& r) { asm volatile("" : "+v"(r)); }
 template <int I> struct IC { static constexpr int value = I; };
 
 template <typename T, int BM, int NW, int SPS, bool F32O, bool C3 = false, int BN = 128, bool PROF = false, int ACT = -1>
-__global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams p) {
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_ring_kernel(const ConvParams p) {
     constexpr int EPC = TypeInfo<T>::EPC, BKE = 8 * EPC;
     static_assert(BN == 128 || BN == 64, "column tile");
     constexpr int WN = BN / 64, WM = NW / WN, TM = BM / WM, TN = 64, MI = TM / 16, NI = 4;  // waves: WM along M x WN along N, 64 columns each
-    constexpr int STAGE = (BM + BN) * 128, NSTAGE = 3;
+    constexpr int STAGE = (BM + BN) * 128;
+    // ring slots: three for the one-workgroup-per-CU builds (8 waves, stage s + 2 issued during step s); two for the 4-wave builds, of which
+    // two workgroups share a CU (separate barriers, so one's waits are the other's MFMA time) and whose stage s + 1 is issued during step s
+    constexpr int NSTAGE = NW == 4 ? 2 : 3, AHEAD = NSTAGE - 1;
     constexpr int NA = BM / 8 / NW, NB = BN / 8 / NW;  // 1-KiB DMA pieces per wave per stage (8 rows x 128 B each)
     constexpr int G = NA + NB;                 // VMEM ops per wave per stage
     constexpr int NGRP = MI / SPS;             // slice groups per tile
@@ -231,9 +244,10 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams 
         begin_issue(slot);
         issue_piece(IC<0>{}); issue_piece(IC<1>{}); issue_piece(IC<2>{}); issue_piece(IC<3>{});
         issue_piece(IC<4>{}); issue_piece(IC<5>{}); issue_piece(IC<6>{}); issue_piece(IC<7>{});
+        issue_piece(IC<8>{}); issue_piece(IC<9>{}); issue_piece(IC<10>{}); issue_piece(IC<11>{});
         end_issue();
     };
-    static_assert(G <= 8 && G <= 2 * NI, "one DMA piece per weight-fragment row of a step");
+    static_assert(G <= 12 && (G <= 2 * NI || NW == 4), "one DMA piece per weight-fragment row of a step");
     constexpr bool SPREAD = !(F32O && MI >= 4);
 
     // the activation is a template parameter (the launcher instantiates the three): no run-time selects inside the slice groups
@@ -257,39 +271,48 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams 
     // channel (inside the wave's 64) of acc[a][.][0] for this lane
     auto ch_of = [&](int a) { return f32o ? 16 * a + 4 * g : 32 * (a >> 1) + 8 * g + 4 * (a & 1); };
 
-    // ---- per-workgroup constant of the epilogue: the bias of the workgroup's 128 channels, parked in LDS behind the ring
+    // ---- per-workgroup constant: the bias of the workgroup's 128 channels, parked in LDS behind the ring.  A tile's accumulators START
+    // at the bias (in the accumulator's scale: f16x2 weights carry a power-of-two factor, so the division is exact) instead of at zero, so
+    // the epilogue neither holds the 16 bias values next to two accumulator sets nor adds them per fragment.
     float* const bias_s = (float*)(smem + NSTAGE * STAGE);
-    if (tid < BN) bias_s[tid] = (p.bias && nt * BN + tid < p.N_g) ? p.bias[nt * BN + tid] : 0.f;
+    if (tid < BN) {
+        const float bsc = IsSplit<T>::value ? 1.f / p.wscale : 1.f;
+        bias_s[tid] = (p.bias && nt * BN + tid < p.N_g) ? p.bias[nt * BN + tid] * bsc : 0.f;
+    }
     __syncthreads();  // (also drains the bias loads: no VMEM op is in flight when the ring starts)
 
     typedef f32x4 Acc[NI][MI];
     Acc accA, accB;
     u32x4 res_r[SPS][4];  // residual of the group in flight: fp32 [j][a] = 4 floats; 16-bit [j][h] = 8 elements, h < 2
 
-    // asm loads of slice group GRP's residual of row tile pmt (every lane loads: out-of-range lanes read the zero page)
+    // asm loads of slice group GRP's residual of row tile pmt: (uniform base) + 32-bit byte offset (host contract: a residual has the
+    // output's geometry or a quarter of it, so it is < 4 GiB like the output).  Every lane loads; lanes past M or N_g read offset 0 --
+    // what they compute is dropped by the range check of the output stores.
+    const char* const res_base = uniform_ptr((const char*)p.res);
     auto load_group = [&](auto GRP, int pmt) {
 #pragma unroll
         for (int j = 0; j < SPS; ++j) {
             const int m = pmt * BM + wm * TM + (decltype(GRP)::value * SPS + j) * 16 + lr;
-            size_t rrow = (size_t)m;  // residual row of output row m
+            unsigned rrow = (unsigned)m;  // residual row of output row m
             if (p.res_mode == RES_UP2) {  // (neck.py:36-38) pixel (img, oh, ow) <- (img, oh / 2, ow / 2) of the half-resolution map
                 const int mm = m < p.M ? m : 0;
                 const int t = fastdiv(mm, p.mg_ow), ow = mm - t * p.OW, img = fastdiv(t, p.mg_oh), oh = t - img * p.OH;
-                rrow = ((size_t)img * (p.OH >> 1) + (oh >> 1)) * (p.OW >> 1) + (ow >> 1);
+                rrow = (unsigned)((img * (p.OH >> 1) + (oh >> 1)) * (p.OW >> 1) + (ow >> 1));
             }
+            const unsigned row_el = m < p.M ? rrow * (unsigned)p.ldr : 0xffffffffu;
             if constexpr (F32O) {
 #pragma unroll
                 for (int a = 0; a < NI; ++a) {
                     const int n = nb + ch_of(a);
-                    const float* src = (m < p.M && n < p.N_g) ? (const float*)p.res + rrow * p.ldr + n : (const float*)p.zero_page;
-                    gload16(res_r[j][a], src);
+                    const unsigned off = (row_el != 0xffffffffu && n < p.N_g) ? (row_el + (unsigned)n) * 4u : 0u;
+                    gload16s(res_r[j][a], res_base, off);
                 }
             } else {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int n = nb + 32 * h + 8 * g;
-                    const T* src = (m < p.M && n < p.N_g) ? (const T*)p.res + rrow * p.ldr + n : (const T*)p.zero_page;
-                    gload16(res_r[j][h], src);
+                    const unsigned off = (row_el != 0xffffffffu && n < p.N_g) ? (row_el + (unsigned)n) * 2u : 0u;
+                    gload16s(res_r[j][h], res_base, off);
                 }
             }
         }
@@ -319,16 +342,11 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams 
         const int RESK = decltype(RES)::value >= 0 ? decltype(RES)::value : res_kind;   // 0 none, 1 raw fp32 (or T for the 16-bit builds), 2 f16x2 chunks
         const bool post = decltype(POST)::value >= 0 ? decltype(POST)::value != 0 : p.res_post != 0;   // activation before the residual add
         const bool outf32 = decltype(OUTF32)::value != 0;
-        // the bias of the wave's four fragments: all LDS reads in flight together, one wait (the operand fragments are dead here, so the
-        // sixteen registers are free)
-        float4 bv[NI];
-#pragma unroll
-        for (int a = 0; a < NI; ++a) bv[a] = *(const float4*)(bias_s + wn * TN + ch_of(a));
-        // one accumulator fragment: weight scale, bias, activation (fragments are fenced with sched_barrier so that the scheduler does not
+        // one accumulator fragment (it started at the bias): weight scale, activation (fragments are fenced with sched_barrier so that the scheduler does not
         // interleave all of a group's GELU polynomials: that costs more registers than the kernel has)
         auto frag = [&](float (&v)[4], const f32x4& c, int a) {
-            v[0] = unscale<T>(c[0], p.wscale) + bv[a].x; v[1] = unscale<T>(c[1], p.wscale) + bv[a].y;
-            v[2] = unscale<T>(c[2], p.wscale) + bv[a].z; v[3] = unscale<T>(c[3], p.wscale) + bv[a].w;
+            v[0] = unscale<T>(c[0], p.wscale); v[1] = unscale<T>(c[1], p.wscale);
+            v[2] = unscale<T>(c[2], p.wscale); v[3] = unscale<T>(c[3], p.wscale);
             if (post) activate(v);
         };
 #pragma unroll
@@ -435,7 +453,7 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams 
     const int nsteps = my_tiles * nk;
     int s = 0;                 // flat step counter: stage s lives in ring slot s % NSTAGE
     bool stored = false;       // the previous step issued a slice group's stores
-    long long tk[4] = {0, 0, 0, 0}, t0 = 0;
+    long long tk[5] = {0, 0, 0, 0, 0}, t0 = 0;
     auto tick = [&](int k) {
         if constexpr (PROF) {
             const long long t = clock64();
@@ -448,10 +466,24 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams 
         constexpr int grp = decltype(GRP)::value;
         // Wait until stage s has landed.  N = VMEM ops issued after stage s's DMAs that may still be outstanding: stage s+1's DMAs and
         // the previous step's stores (its residual loads were consumed, hence complete; VMEM ops retire in issue order).
-        if (s + 1 < nsteps) {
-            if (!stored) wait_vm_barrier<G>(); else wait_vm_barrier<G + SG>();
+        auto wait_stage = [&](auto NN) {
+            constexpr int N = decltype(NN)::value;
+#ifdef OCRVI_TIMING_RING_NOBAR   // (development: no barrier -- races, timing only)
+            wait_vm_only<N>();
+#else
+            if constexpr (PROF) {   // the wave's own DMA pieces (slot 4 of the report), then the workgroup (slot 0)
+                wait_vm_only<N>();
+                tick(4);
+                asm volatile("s_barrier" ::: "memory");
+            } else {
+                wait_vm_barrier<N>();
+            }
+#endif
+        };
+        if (AHEAD > 1 && s + 1 < nsteps) {
+            if (!stored) wait_stage(IC<G>{}); else wait_stage(IC<G + SG>{});
         } else {
-            if (!stored) wait_vm_barrier<0>(); else wait_vm_barrier<SG>();
+            if (!stored) wait_stage(IC<0>{}); else wait_stage(IC<SG>{});
         }
         tick(0);
         bool run = false;
@@ -459,8 +491,8 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams 
             run = parked;
             if (run && has_res) load_group(GRP, pmt);
         }
-        const bool dma = s + 2 < nsteps;
-        if (dma) begin_issue((s + 2) % NSTAGE);
+        const bool dma = s + AHEAD < nsteps;
+        if (dma) begin_issue((s + AHEAD) % NSTAGE);
         tick(1);
         const char* As = smem + (s % NSTAGE) * STAGE;
         const char* Bs = As + BM * 128;
@@ -492,6 +524,7 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams 
             if (dma) {
                 issue_piece(IC<0>{}); issue_piece(IC<1>{}); issue_piece(IC<2>{}); issue_piece(IC<3>{});
                 issue_piece(IC<4>{}); issue_piece(IC<5>{}); issue_piece(IC<6>{}); issue_piece(IC<7>{});
+                issue_piece(IC<8>{}); issue_piece(IC<9>{}); issue_piece(IC<10>{}); issue_piece(IC<11>{});
             }
         }
         if constexpr (IsSplit<T>::value) {
@@ -504,8 +537,8 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams 
             // regrouping moves fall under the previous row's MFMAs instead of in front of its own
             auto wread = [&](int a, uint4& c0, uint4& c1) {
                 const char* r = Bs + (wn * TN + a_row(a) + brow) * 128;
-                c0 = *(const uint4*)(r + fob0);
-                c1 = *(const uint4*)(r + fob1);
+                c0 = lds16(r + fob0);
+                c1 = lds16(r + fob1);
             };
             auto sgroup = [&](auto B0) {
                 constexpr int b0 = decltype(B0)::value;
@@ -515,7 +548,7 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams 
 #pragma unroll
                 for (int b = 0; b < XB; ++b) {
                     const char* r = As + (wm * TM + (b0 + b) * 16 + lr) * 128;
-                    Mma<T>::regroup(*(const uint4*)(r + foa0), *(const uint4*)(r + foa1), xH[b], xL[b]);
+                    Mma<T>::regroup(lds16(r + foa0), lds16(r + foa1), xH[b], xL[b]);
                 }
                 auto srow = [&](auto A) {
                     constexpr int a = decltype(A)::value;
@@ -535,10 +568,40 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams 
                 };
                 srow(IC<0>{}); srow(IC<1>{}); srow(IC<2>{}); srow(IC<3>{});
             };
-            sgroup(IC<0>{});
-            if constexpr (MI > XB) {
+            if constexpr (grp < 0 && MI > XB) {
+                // steady step (no parked tile: its accumulator set and the epilogue's registers are dead here): every fragment of the step is
+                // requested up front -- 16 reads, the weights once -- so one LDS latency is exposed per step instead of one per group plus a
+                // partial one per weight row
+                uint4 n0, n1, xr[MI][2];
+                wread(0, n0, n1);
+#pragma unroll
+                for (int b = 0; b < MI; ++b) {
+                    const char* r = As + (wm * TM + b * 16 + lr) * 128;
+                    xr[b][0] = lds16(r + foa0);
+                    xr[b][1] = lds16(r + foa1);
+                }
                 __builtin_amdgcn_sched_barrier(0);
-                sgroup(IC<XB>{});
+                U xH[MI], xL[MI];
+#pragma unroll
+                for (int b = 0; b < MI; ++b) Mma<T>::regroup(xr[b][0], xr[b][1], xH[b], xL[b]);
+                // weight rows one row = 12 MFMAs ahead, requested BEFORE the row's MFMAs (fenced: hipcc otherwise sinks the reads to a few MFMAs
+                // before their use and waits on them at once)
+#pragma unroll
+                for (int a = 0; a < NI; ++a) {
+                    U wH, wL;
+                    Mma<T>::regroup(n0, n1, wH, wL);
+                    if (a + 1 < NI) wread(a + 1, n0, n1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int b = 0; b < MI; ++b) Mma<T>::three(wH, wL, xH[b], xL[b], acc[a][b]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                sgroup(IC<0>{});
+                if constexpr (MI > XB) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    sgroup(IC<XB>{});
+                }
             }
         } else {
             half(IC<0>{});
@@ -562,9 +625,11 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams 
     // One tile into acc; the parked tile's NGRP slice groups ride on its first NGRP K-steps (NGRP <= nk by the host contract).
     auto tile = [&](Acc& acc, Acc& pnd, bool parked, int pmt) {
 #pragma unroll
-        for (int a = 0; a < NI; ++a)
+        for (int a = 0; a < NI; ++a) {
+            const float4 bv = *(const float4*)(bias_s + wn * TN + ch_of(a));
 #pragma unroll
-            for (int b = 0; b < MI; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int b = 0; b < MI; ++b) acc[a][b] = (f32x4){bv.x, bv.y, bv.z, bv.w};
+        }
         if constexpr (NGRP >= 1) step(acc, pnd, IC<0>{}, parked, pmt);
         if constexpr (NGRP >= 2) step(acc, pnd, IC<1>{}, parked, pmt);
         if constexpr (NGRP >= 3) step(acc, pnd, IC<2>{}, parked, pmt);
@@ -589,7 +654,7 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams 
 
     setup_issue(i_mt);
     issue_stage(0);
-    if (nsteps > 1) issue_stage(1);
+    if (AHEAD > 1 && nsteps > 1) issue_stage(1);
     if constexpr (PROF) t0 = clock64();
     int mt = mt0;
     bool parked = false;  // a finished tile sits in the other accumulator set
@@ -607,7 +672,7 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams 
     tick(3);
     if constexpr (PROF) {
         if (lane == 0)
-            for (int k = 0; k < 4; ++k) atomicAdd((unsigned long long*)p.out2 + k, (unsigned long long)tk[k]);
+            for (int k = 0; k < 5; ++k) atomicAdd((unsigned long long*)p.out2 + k, (unsigned long long)tk[k]);
     }
 }
 

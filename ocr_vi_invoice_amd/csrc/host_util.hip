@@ -252,6 +252,8 @@ bool gemm_ring_eligible(const ConvParams& p, int amode, int dtype) {
     if (p.bias && ((uintptr_t)p.bias & 15) != 0) return false;
     // the epilogue addresses the output with 32-bit byte offsets through a buffer descriptor
     if (((size_t)(p.M - 1) * p.ldo + p.out_coff + p.N_g) * (of32 ? 4 : 2) >= ((size_t)1 << 32) - 65536) return false;
+    // ... and the residual with 32-bit byte offsets from its base (it has at most the output's rows)
+    if (p.res_mode != RES_NONE && ((size_t)(p.M - 1) * p.ldr + p.N_g) * (rf32 ? 4 : 2) >= ((size_t)1 << 32) - 65536) return false;
     return true;
 }
 
