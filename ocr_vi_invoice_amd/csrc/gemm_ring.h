@@ -118,7 +118,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_ring_kernel(con
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int lr = lane & 15, g = lane >> 4;
+    int lr = lane & 15, g = lane >> 4;        // (not const: drain() recomputes them, see there)
     constexpr bool f32o = F32O;                                   // output (and residual) element type: fp32 or T
     static_assert(F32O || sizeof(T) == 2, "an fp32 GEMM has fp32 output");
     const bool has_res = p.res_mode != RES_NONE;                  // RES_SAME, or RES_UP2: nearest 2x upsample of a half-resolution tensor
@@ -568,7 +568,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_ring_kernel(con
                 };
                 srow(IC<0>{}); srow(IC<1>{}); srow(IC<2>{}); srow(IC<3>{});
             };
-            if constexpr (grp < 0 && MI > XB) {
+            if constexpr (MI > XB) {
                 // steady step (no parked tile: its accumulator set and the epilogue's registers are dead here): every fragment of the step is
                 // requested up front -- 16 reads, the weights once -- so one LDS latency is exposed per step instead of one per group plus a
                 // partial one per weight row
@@ -638,6 +638,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_ring_kernel(con
         for (int ks = NGRP; ks < nk; ++ks) step(acc, pnd, IC<-1>{}, false, pmt);
     };
     auto drain = [&](Acc& pnd, int pmt) {  // the last tile's epilogue (no DMA is in flight any more)
+        {   // the lane's fragment coordinates are needed again only here: recomputed from an opaque copy of the thread index, so that the
+            // register allocator does not carry (or spill) them through the whole ring loop for this one use
+            int l = threadIdx.x;
+            asm volatile("" : "+v"(l));
+            lr = l & 15;
+            g = (l & 63) >> 4;
+        }
         auto one = [&](auto GRP) {
             if (has_res) {
                 load_group(GRP, pmt);
