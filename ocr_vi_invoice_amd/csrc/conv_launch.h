@@ -27,7 +27,7 @@ static int launch_tile(const ConvParams& p, hipStream_t stream) {
 
 template <typename T, int BM, int NW, int SPS, bool F32O, bool C3, int BN, int ACT>
 static int launch_ring_act(const ConvParams& p, int grid, hipStream_t stream) {
-    constexpr int smem = (NW == 4 ? 2 : 3) * (BM + BN) * 128 + 512;  // ring + bias
+    constexpr int smem = 3 * (BM + BN) * 128 + 512;  // ring + bias
     auto kern = gemm_ring_kernel<T, BM, NW, SPS, F32O, C3, BN, false, ACT>;
     OCRVI_TRY(ensure_max_smem((const void*)kern, smem));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), smem, stream, p);
@@ -37,7 +37,7 @@ static int launch_ring_act(const ConvParams& p, int grid, hipStream_t stream) {
 
 template <typename T, int BM, int NW, int SPS, bool F32O, bool C3, int BN = 128>
 static int launch_ring_f(const ConvParams& p, int grid, hipStream_t stream) {
-    constexpr int smem = (NW == 4 ? 2 : 3) * (BM + BN) * 128 + 512;  // ring + bias
+    constexpr int smem = 3 * (BM + BN) * 128 + 512;  // ring + bias
 #ifdef OCRVI_RING_PROF_BUILD
     static const bool prof = getenv("OCRVI_RING_PROF") && atoi(getenv("OCRVI_RING_PROF"));
     if (prof) {  // development aid: cycle breakdown per phase, printed per launch (synchronises)

@@ -98,14 +98,12 @@ __device__ __forceinline__ uint4 lds16(const char* p) {
 template <int I> struct IC { static constexpr int value = I; };
 
 template <typename T, int BM, int NW, int SPS, bool F32O, bool C3 = false, int BN = 128, bool PROF = false, int ACT = -1>
-__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_ring_kernel(const ConvParams p) {
+__global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams p) {
     constexpr int EPC = TypeInfo<T>::EPC, BKE = 8 * EPC;
     static_assert(BN == 128 || BN == 64, "column tile");
     constexpr int WN = BN / 64, WM = NW / WN, TM = BM / WM, TN = 64, MI = TM / 16, NI = 4;  // waves: WM along M x WN along N, 64 columns each
     constexpr int STAGE = (BM + BN) * 128;
-    // ring slots: three for the one-workgroup-per-CU builds (8 waves, stage s + 2 issued during step s); two for the 4-wave builds, of which
-    // two workgroups share a CU (separate barriers, so one's waits are the other's MFMA time) and whose stage s + 1 is issued during step s
-    constexpr int NSTAGE = NW == 4 ? 2 : 3, AHEAD = NSTAGE - 1;
+    constexpr int NSTAGE = 3, AHEAD = NSTAGE - 1;   // ring slots; stage s + AHEAD is issued during step s
     constexpr int NA = BM / 8 / NW, NB = BN / 8 / NW;  // 1-KiB DMA pieces per wave per stage (8 rows x 128 B each)
     constexpr int G = NA + NB;                 // VMEM ops per wave per stage
     constexpr int NGRP = MI / SPS;             // slice groups per tile
@@ -244,10 +242,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_ring_kernel(con
         begin_issue(slot);
         issue_piece(IC<0>{}); issue_piece(IC<1>{}); issue_piece(IC<2>{}); issue_piece(IC<3>{});
         issue_piece(IC<4>{}); issue_piece(IC<5>{}); issue_piece(IC<6>{}); issue_piece(IC<7>{});
-        issue_piece(IC<8>{}); issue_piece(IC<9>{}); issue_piece(IC<10>{}); issue_piece(IC<11>{});
         end_issue();
     };
-    static_assert(G <= 12 && (G <= 2 * NI || NW == 4), "one DMA piece per weight-fragment row of a step");
+    static_assert(G <= 8 && G <= 2 * NI, "one DMA piece per weight-fragment row of a step");
     constexpr bool SPREAD = !(F32O && MI >= 4);
 
     // the activation is a template parameter (the launcher instantiates the three): no run-time selects inside the slice groups
@@ -524,8 +521,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_ring_kernel(con
             if (dma) {
                 issue_piece(IC<0>{}); issue_piece(IC<1>{}); issue_piece(IC<2>{}); issue_piece(IC<3>{});
                 issue_piece(IC<4>{}); issue_piece(IC<5>{}); issue_piece(IC<6>{}); issue_piece(IC<7>{});
-                issue_piece(IC<8>{}); issue_piece(IC<9>{}); issue_piece(IC<10>{}); issue_piece(IC<11>{});
-            }
+                    }
         }
         if constexpr (IsSplit<T>::value) {
             // f16x2: both chunks of every fragment at once, regrouped into (hi, lo) quartets: three MFMAs per fragment pair (Mma<f16x2_t>)
