@@ -98,7 +98,8 @@ __device__ __forceinline__ uint4 lds16(const char* p) {
 template <int I> struct IC { static constexpr int value = I; };
 
 template <typename T, int BM, int NW, int SPS, bool F32O, bool C3 = false, int BN = 128, bool PROF = false, int ACT = -1>
-__global__ __launch_bounds__(NW * 64, 1) void gemm_ring_kernel(const ConvParams p) {
+// (second launch bound = waves per SIMD in HIP: NW / 4 of them share a SIMD's 512 registers)
+__global__ __launch_bounds__(NW * 64, NW / 4) void gemm_ring_kernel(const ConvParams p) {
     constexpr int EPC = TypeInfo<T>::EPC, BKE = 8 * EPC;
     static_assert(BN == 128 || BN == 64, "column tile");
     constexpr int WN = BN / 64, WM = NW / WN, TM = BM / WM, TN = 64, MI = TM / 16, NI = 4;  // waves: WM along M x WN along N, 64 columns each
