@@ -368,11 +368,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gemm_ring_kernel(const ConvPa
                     }
                     if (!post) activate(v);
                     const int c = ch_of(a);
-#ifdef OCRVI_TIMING_RING_OOB_STORES   /* timing experiment only: every store instruction issues but the range check drops all of its lanes */
-                    const unsigned off = OOB;
-#else
                     const unsigned off = (row_b != OOB && nb + c < p.N_g) ? row_b + (unsigned)c * 4u : OOB;
-#endif
                     u32x4 pk;
                     if (IsSplit<T>::value && !outf32) {
                         const uint4 e = Chunk<T>::pack(v);
