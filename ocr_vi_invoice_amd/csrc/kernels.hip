@@ -18,6 +18,20 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+// 64-lane sum without the LDS crossbar: four DPP adds leave every 16-lane row's total in all of its lanes, the four row totals are read
+// into SGPRs and added (the result is wave-uniform).  ~12 full-rate VALU instructions against 6 dependent ds_bpermute round trips.
+template <int CTRL> __device__ __forceinline__ float dpp_add(float x) {
+    return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wave_sum_uniform(float v) {
+    v = dpp_add<0xB1>(v);      // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);      // quad_perm [2,3,0,1]
+    v = dpp_add<0x124>(v);     // row_ror:4
+    v = dpp_add<0x128>(v);     // row_ror:8
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (r0 + r1) + (r2 + r3);
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
@@ -403,6 +417,152 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+// 4-byte element types (fp32, f16x2): all 64 lanes of a wave share ONE pixel (64 x 4 channels), so a pixel's twelve coarse taps are
+// wave-uniform.  The per-pixel form above, run that way, is bound by LATENCY: one pixel in flight per wave, 13 dependent loads each
+// (6300 cycles per pixel and wave, 1583 us for 16 pages against ~500 us of HBM time).  Here a wave walks DOWN one column of ASF_TALL
+// pixels: the taps' columns never change and their rows advance by at most one per pixel, so every level keeps three tap rows in
+// registers -- (top, bottom) in use and the row after them already requested -- and p2 runs four pixels ahead; in the steady state no
+// load is waited for.  The four waves of a workgroup take four adjacent columns (their coarse taps overlap in L1).  The arithmetic is
+// asf_blend_kernel's except for the order of the 64-lane score sums (DPP row sums + four row totals instead of a butterfly).
+constexpr int ASF_TALL = 48;
+template <typename T>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void asf_blend_col_kernel(const T* __restrict__ p2, const T* __restrict__ p3, const T* __restrict__ p4,
+                                                        const T* __restrict__ p5, const float* __restrict__ s3, const float* __restrict__ s4,
+                                                        const float* __restrict__ s5, const float* __restrict__ w, const float* __restrict__ bias,
+                                                        T* __restrict__ out, int N, int H, int W) {
+    static_assert(TypeInfo<T>::EPC == 4, "one pixel per wave");
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float w0[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float4 t = *(const float4*)(w + i * 1024 + lane * 4);
+        w0[i][0] = t.x; w0[i][1] = t.y; w0[i][2] = t.z; w0[i][3] = t.w;
+    }
+    const float4 bv = *(const float4*)bias;
+    const T* lev[3] = {p3, p4, p5};
+    const float* slev[3] = {s3, s4, s5};
+    const int strips = W >> 2, segs = (H + ASF_TALL - 1) / ASF_TALL;
+    const int ntask = N * segs * strips;
+    float shl[3], swl[3];
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+        shl[l] = H > 1 ? (float)((H >> (l + 1)) - 1) / (float)(H - 1) : 0.f;
+        swl[l] = W > 1 ? (float)((W >> (l + 1)) - 1) / (float)(W - 1) : 0.f;
+    }
+    for (int task = blockIdx.x; task < ntask; task += gridDim.x) {
+        const int sx = task % strips, tt = task / strips, sg = tt % segs, n = tt / segs;
+        const int x = sx * 4 + wv;
+        const int ya = sg * ASF_TALL, yb = min(ya + ASF_TALL, H);      // rows [ya, yb) of column x
+        // ---- per level: the taps' column pair and its weights, and three tap rows: slots 0,1 = (top, x0 / x1), 2,3 = bottom, 4,5 = next
+        int cx0[3], cx1[3], cy0[3], base[3];
+        float clx[3];
+        uint4 tap[3][6];
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+            const int Hl = H >> (l + 1), Wl = W >> (l + 1);
+            const float fx = swl[l] * (float)x;
+            const int x0 = (int)fx;
+            cx0[l] = x0;
+            cx1[l] = x0 + (x0 < Wl - 1 ? 1 : 0);
+            clx[l] = fx - (float)x0;
+            base[l] = n * Hl * Wl;
+            const int y0 = __builtin_amdgcn_readfirstlane((int)(shl[l] * (float)ya));
+            cy0[l] = y0;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int row = min(y0 + r, Hl - 1);
+                tap[l][2 * r] = *(const uint4*)(lev[l] + (size_t)(base[l] + row * Wl + cx0[l]) * 256 + lane * 4);
+                tap[l][2 * r + 1] = *(const uint4*)(lev[l] + (size_t)(base[l] + row * Wl + cx1[l]) * 256 + lane * 4);
+            }
+        }
+        const T* const pcol = p2 + (((size_t)n * H + ya) * W + x) * 256 + lane * 4;
+        T* const ocol = out + (((size_t)n * H + ya) * W + x) * 256 + lane * 4;
+        const size_t rowstep = (size_t)W * 256;
+        const int rows = yb - ya;
+        uint4 ring[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ring[k] = *(const uint4*)(pcol + (size_t)min(k, rows - 1) * rowstep);
+        auto pixel = [&](int yy, uint4& slot) {
+            const int y = ya + yy;
+            float f0[4];
+            Chunk<T>::unpack(slot, f0);
+            slot = *(const uint4*)(pcol + (size_t)min(yy + 4, rows - 1) * rowstep);     // four pixels ahead
+            // tap rows of this pixel; the coarse score vectors are wave-uniform loads (scalar), requested before the reductions below
+            float tw[3][4];
+            float4 sv[3][4];
+#pragma unroll
+            for (int l = 0; l < 3; ++l) {
+                const int Hl = H >> (l + 1), Wl = W >> (l + 1);
+                const float fy = shl[l] * (float)y;
+                const int y0 = __builtin_amdgcn_readfirstlane((int)fy);
+                if (y0 != cy0[l]) {      // wave-uniform: the rows advance by one; request the row after the new bottom row
+                    tap[l][0] = tap[l][2]; tap[l][1] = tap[l][3];
+                    tap[l][2] = tap[l][4]; tap[l][3] = tap[l][5];
+                    const int row = min(y0 + 2, Hl - 1);
+                    tap[l][4] = *(const uint4*)(lev[l] + (size_t)(base[l] + row * Wl + cx0[l]) * 256 + lane * 4);
+                    tap[l][5] = *(const uint4*)(lev[l] + (size_t)(base[l] + row * Wl + cx1[l]) * 256 + lane * 4);
+                    cy0[l] = y0;
+                }
+                const int y1 = y0 + (y0 < Hl - 1 ? 1 : 0);
+                const float ly = fy - (float)y0, lx = clx[l], hy = 1.f - ly, hx = 1.f - lx;
+                tw[l][0] = hy * hx; tw[l][1] = hy * lx; tw[l][2] = ly * hx; tw[l][3] = ly * lx;
+                const int o00 = __builtin_amdgcn_readfirstlane(base[l] + y0 * Wl + cx0[l]), o01 = __builtin_amdgcn_readfirstlane(base[l] + y0 * Wl + cx1[l]);
+                const int o10 = __builtin_amdgcn_readfirstlane(base[l] + y1 * Wl + cx0[l]), o11 = __builtin_amdgcn_readfirstlane(base[l] + y1 * Wl + cx1[l]);
+                sv[l][0] = *(const float4*)(slev[l] + (size_t)o00 * 4); sv[l][1] = *(const float4*)(slev[l] + (size_t)o01 * 4);
+                sv[l][2] = *(const float4*)(slev[l] + (size_t)o10 * 4); sv[l][3] = *(const float4*)(slev[l] + (size_t)o11 * 4);
+            }
+            float sc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float a = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a = fmaf(w0[i][e], f0[e], a);
+                sc[i] = wave_sum_uniform(a);
+            }
+            sc[0] += bv.x; sc[1] += bv.y; sc[2] += bv.z; sc[3] += bv.w;
+#pragma unroll
+            for (int l = 0; l < 3; ++l)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    sc[0] = fmaf(tw[l][q], sv[l][q].x, sc[0]); sc[1] = fmaf(tw[l][q], sv[l][q].y, sc[1]);
+                    sc[2] = fmaf(tw[l][q], sv[l][q].z, sc[2]); sc[3] = fmaf(tw[l][q], sv[l][q].w, sc[3]);
+                }
+            const float mx = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+            float den = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { sc[i] = __expf(sc[i] - mx); den += sc[i]; }
+            const float inv = 1.f / den;
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = f0[e] * (sc[0] * inv);
+#pragma unroll
+            for (int l = 0; l < 3; ++l) {
+                const float al = sc[l + 1] * inv;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float cf = al * tw[l][q];
+                    if constexpr (IsSplit<T>::value) {
+                        Chunk<T>::fma(tap[l][q], cf, o);      // both halves of every channel in mixed-precision fmas, no conversions
+                    } else {
+                        float f[4];
+                        Chunk<T>::unpack(tap[l][q], f);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = fmaf(cf, f[e], o[e]);
+                    }
+                }
+            }
+            *(uint4*)(ocol + (size_t)yy * rowstep) = Chunk<T>::pack(o);
+        };
+#pragma unroll 1
+        for (int yy = 0; yy < rows; yy += 4) {      // unrolled by four so that the p2 ring has static slots
+            pixel(yy, ring[0]);
+            if (yy + 1 < rows) pixel(yy + 1, ring[1]);
+            if (yy + 2 < rows) pixel(yy + 2, ring[2]);
+            if (yy + 3 < rows) pixel(yy + 3, ring[3]);
+        }
+    }
+}
+
 template <typename T>
 static void asf_launch(const void* p2, const void* p3, const void* p4, const void* p5, const float* w, const float* b, float* s3, float* s4,
                        float* s5, void* out, int N, int H, int W, hipStream_t s) {
@@ -415,8 +575,14 @@ static void asf_launch(const void* p2, const void* p3, const void* p4, const voi
     }
     const size_t total = (size_t)N * H * W;
     const int grid = (int)std::min<size_t>(total / 64, 256 * 8);
-    hipLaunchKernelGGL(asf_blend_kernel<T>, dim3(grid), dim3(256), 0, s, (const T*)p2, (const T*)p3, (const T*)p4, (const T*)p5, s3, s4, s5, w, b,
-                       (T*)out, N, H, W);
+    if constexpr (TypeInfo<T>::EPC == 4) {
+        const int ntask = N * ((H + ASF_TALL - 1) / ASF_TALL) * (W / 4);       // (column strip of four, ASF_TALL rows) per workgroup pass
+        hipLaunchKernelGGL(asf_blend_col_kernel<T>, dim3(std::min(ntask, 512)), dim3(256), 0, s, (const T*)p2, (const T*)p3, (const T*)p4, (const T*)p5, s3, s4, s5, w, b,
+                           (T*)out, N, H, W);
+    } else {
+        hipLaunchKernelGGL(asf_blend_kernel<T>, dim3(grid), dim3(256), 0, s, (const T*)p2, (const T*)p3, (const T*)p4, (const T*)p5, s3, s4, s5, w, b,
+                           (T*)out, N, H, W);
+    }
 }
 
 int k_asf(int dtype, const void* p2, const void* p3, const void* p4, const void* p5, const float* w, const float* b, float* scratch, void* out,
