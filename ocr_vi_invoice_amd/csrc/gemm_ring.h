@@ -269,12 +269,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gemm_ring_kernel(const ConvPa
     // channel (inside the wave's 64) of acc[a][.][0] for this lane
     auto ch_of = [&](int a) { return f32o ? 16 * a + 4 * g : 32 * (a >> 1) + 8 * g + 4 * (a & 1); };
 
-    // ---- per-workgroup constant: the bias of the workgroup's 128 channels, parked in LDS behind the ring.  In the fp32-output builds a
+    // ---- per-workgroup constant: the bias of the workgroup's 128 channels, parked in LDS behind the ring.  In the fp32 / f16x2 builds a
     // tile's accumulators START at the bias (in the accumulator's scale: f16x2 weights carry a power-of-two factor, so the division is
     // exact) instead of at zero, so the epilogue neither holds the 16 bias values next to two accumulator sets nor adds them per fragment.
-    // The 16-bit-output builds add it in the epilogue like every other kernel of the library: their 3x3 mode shares layers with
+    // The 16-bit builds add it in the epilogue like every other kernel of the library: their 3x3 mode shares layers with
     // conv_gemm_kernel (by M), and the two must round identically for a page to come out the same alone and inside a batch.
-    constexpr bool BIAS_FIRST = F32O;
+    constexpr bool BIAS_FIRST = sizeof(T) == 4;
     float* const bias_s = (float*)(smem + NSTAGE * STAGE);
     if (tid < BN) {
         const float bsc = IsSplit<T>::value ? 1.f / p.wscale : 1.f;
@@ -343,14 +343,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gemm_ring_kernel(const ConvPa
         const int RESK = decltype(RES)::value >= 0 ? decltype(RES)::value : res_kind;   // 0 none, 1 raw fp32 (or T for the 16-bit builds), 2 f16x2 chunks
         const bool post = decltype(POST)::value >= 0 ? decltype(POST)::value != 0 : p.res_post != 0;   // activation before the residual add
         const bool outf32 = decltype(OUTF32)::value != 0;
-        // (16-bit-output builds: the bias of the wave's four fragments, all LDS reads in flight together -- the operand fragments are dead
+        // (16-bit builds: the bias of the wave's four fragments, all LDS reads in flight together -- the operand fragments are dead
         // here, so the sixteen registers are free)
         float4 bv[NI];
         if constexpr (!BIAS_FIRST) {
 #pragma unroll
             for (int a = 0; a < NI; ++a) bv[a] = *(const float4*)(bias_s + wn * TN + ch_of(a));
         }
-        // one accumulator fragment (which started at the bias in the fp32-output builds): weight scale, bias, activation (fragments are fenced with sched_barrier so that the scheduler does not
+        // one accumulator fragment (which started at the bias in the fp32 / f16x2 builds): weight scale, bias, activation (fragments are fenced with sched_barrier so that the scheduler does not
         // interleave all of a group's GELU polynomials: that costs more registers than the kernel has)
         auto frag = [&](float (&v)[4], const f32x4& c, int a) {
             v[0] = unscale<T>(c[0], p.wscale); v[1] = unscale<T>(c[1], p.wscale);

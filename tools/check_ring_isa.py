@@ -25,9 +25,11 @@ def kernel_bodies(asm_text, prefix="_ZN5ocrvi16gemm_ring_kernel"):
         body, inasm = [], False
         for t in lines[i + 1:]:
             t = t.strip()
+            if t.startswith(".Lfunc_end"):        # (not the first s_endpgm: the block layout may put an exit path ahead of the main loop)
+                break
             if "s_endpgm" in t:
                 body.append(("s_endpgm", False))
-                break
+                continue
             if "#ASMSTART" in t:
                 inasm = True
                 continue
@@ -96,7 +98,8 @@ def check(src):
         scratch = sum("scratch_" in t for t, _ in body)
         touches, loads = [], 0
         for i, (t, a) in enumerate(body):
-            m = re.match(r"global_load_dwordx4 v\[(\d+):(\d+)\], v\[\d+:\d+\], off$", t)
+            # the residual loads: (64-bit address, off) or (32-bit offset, SGPR base) form
+            m = re.match(r"global_load_dwordx4 v\[(\d+):(\d+)\], (?:v\[\d+:\d+\], off|v\d+, s\[\d+:\d+\])$", t)
             if not (m and a):
                 continue
             loads += 1
