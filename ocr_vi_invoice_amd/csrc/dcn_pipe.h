@@ -194,30 +194,59 @@ __global__ __launch_bounds__(512, 2) void dcn_pipe_kernel(const ConvParams p) {
 
         // ---- prologue.  VMEM queue order per step: gathers first, weight stage second, so that "all but the GW youngest" covers
         // the gathers the next blend needs and leaves the newest weight stage in flight.
+        // The two waves of a SIMD (w and w + 4) run the step's two halves in opposite order, so that one blends (VALU) while the other
+        // multiplies (matrix pipe) instead of both doing the same thing behind the step's barrier:
+        //   waves 0-3:  wait + barrier | gathers(s+2) -> the other register set, weights(s+2) | blend(s+1) | MFMA(s)
+        //   waves 4-7:  wait + barrier | weights(s+2) | MFMA(s) | blend(s+1) | gathers(s+2) -> the SAME register set (one set is enough:
+        //               it is refilled right after the blend has consumed it, and has until the end of the next step to land)
+        // Both orders finish blend(s+1) and MFMA(s) inside step s, so the slab / weight-ring hand-over at the barrier is unchanged; the
+        // counted waits differ because the VMEM queue order does (waves 4-7: weights(s+1), gathers(s+1), weights(s+2), ...).
         GSet SA, SB;
-        issue_w(0);
-        issue_gather(0, SA);
-        if (nk > 1) {
-            issue_gather(1, SB);
-            issue_w(1);
-            wait_vm_only<GG + GW>();
-        } else {
+        if (wave & 4) {
+            issue_w(0);
+            issue_gather(0, SA);
             wait_vm_only<0>();
-        }
-        blend(0, SA);
-        // ---- steady state, unrolled by two so the register sets have static names:  step s blends s + 1 and multiplies s
-        auto step = [&](int s, GSet& Sblend, GSet& Snext) {
-            if (s + 1 < nk) wait_vm_barrier<GW>(); else wait_vm_barrier<0>();
-            if (s + 2 < nk) {
-                issue_gather(s + 2, Snext);
-                issue_w(s + 2);
+            blend(0, SA);
+            if (nk > 1) {
+                issue_w(1);
+                issue_gather(1, SA);
             }
-            if (s + 1 < nk) blend(s + 1, Sblend);
-            mma(s);
-        };
-        for (int s = 0; s < nk; s += 2) {
-            step(s, SB, SA);          // blends s + 1 (set B), refills set A with s + 2
-            if (s + 1 < nk) step(s + 1, SA, SB);
+            for (int s = 0; s < nk; ++s) {
+                // stage s has landed once everything but weights(s+1) and gathers(s+1) is done
+                if (s + 1 < nk) wait_vm_barrier<GG + GW>(); else wait_vm_barrier<0>();
+                if (s + 2 < nk) issue_w(s + 2);
+                mma(s);
+                if (s + 1 < nk) {
+                    if (s + 2 < nk) wait_vm_only<GW>(); else wait_vm_only<0>();      // gathers(s+1): only weights(s+2) is younger
+                    blend(s + 1, SA);
+                    if (s + 2 < nk) issue_gather(s + 2, SA);
+                }
+            }
+        } else {
+            issue_w(0);
+            issue_gather(0, SA);
+            if (nk > 1) {
+                issue_gather(1, SB);
+                issue_w(1);
+                wait_vm_only<GG + GW>();
+            } else {
+                wait_vm_only<0>();
+            }
+            blend(0, SA);
+            // ---- steady state, unrolled by two so the register sets have static names:  step s blends s + 1 and multiplies s
+            auto step = [&](int s, GSet& Sblend, GSet& Snext) {
+                if (s + 1 < nk) wait_vm_barrier<GW>(); else wait_vm_barrier<0>();
+                if (s + 2 < nk) {
+                    issue_gather(s + 2, Snext);
+                    issue_w(s + 2);
+                }
+                if (s + 1 < nk) blend(s + 1, Sblend);
+                mma(s);
+            };
+            for (int s = 0; s < nk; s += 2) {
+                step(s, SB, SA);          // blends s + 1 (set B), refills set A with s + 2
+                if (s + 1 < nk) step(s + 1, SA, SB);
+            }
         }
         // ---- epilogue: bias + activation; one 16-byte store per lane (16-bit: 8 consecutive channels thanks to the row permutation,
         // fp32: the accumulator's 4), 64 contiguous bytes per pixel and instruction
