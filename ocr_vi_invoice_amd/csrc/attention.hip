@@ -39,8 +39,10 @@ template <> __device__ __forceinline__ f32x4 mfma16<f16_t>(const uint4& a, const
 // then no key masking is generated at all.
 // NWV = waves per workgroup (they share the staged K / V^T): 8 for the fp32 480-key case, whose 123 KB of LDS allow one workgroup per CU --
 // with 4 waves that is one wave per SIMD and nothing to hide a wave's LDS latency and softmax behind.
+// (f16x2 up to 256 keys: 8 waves per workgroup at no more than 128 registers, so that the two workgroups a CU's LDS holds give every SIMD four waves:
+// a wave's QK -> softmax -> PV chain is latency-bound and needs neighbours)
 template <typename T, int MAXT, bool MASK, int NWV = 4>
-__global__ __launch_bounds__(NWV * 64) void attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int N, int heads) {
+__global__ __launch_bounds__(NWV * 64, (IsSplit<T>::value && MAXT <= 16 && NWV == 8) ? 4 : 1) void attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int N, int heads) {
     constexpr int EPC = TypeInfo<T>::EPC;
     constexpr int KROW = AttnCfg<T>::KROW;
     constexpr int CH = KROW / 16;  // 16-byte chunks per K row
@@ -437,6 +439,16 @@ static int launch_attn_m(const void* qkv, void* out, int B, int N, int heads, hi
     const int smem = NP * AttnCfg<T>::KROW + 32 * AttnCfg<T>::vstride(NP);
     if constexpr (sizeof(T) == 4 && MAXT >= 30) {
         static const bool w8 = !(getenv("OCRVI_ATTN_F32_W8") && atoi(getenv("OCRVI_ATTN_F32_W8")) == 0);   // A/B switch
+        if (w8) {
+            auto kern8 = attention_kernel<T, MAXT, MASK, 8>;
+            OCRVI_TRY(ensure_max_smem((const void*)kern8, smem));
+            hipLaunchKernelGGL(kern8, dim3(heads * B), dim3(512), smem, s, (const T*)qkv, (T*)out, N, heads);
+            OCRVI_HIP(hipGetLastError());
+            return OCRVI_OK;
+        }
+    }
+    if constexpr (IsSplit<T>::value && MAXT >= 15 && MAXT <= 16) {
+        static const bool w8 = !(getenv("OCRVI_ATTN_X2_W8") && atoi(getenv("OCRVI_ATTN_X2_W8")) == 0);   // A/B switch
         if (w8) {
             auto kern8 = attention_kernel<T, MAXT, MASK, 8>;
             OCRVI_TRY(ensure_max_smem((const void*)kern8, smem));
