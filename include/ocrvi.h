@@ -30,7 +30,13 @@ extern "C" {
  * OCRVI_F32   fp32 operands on v_mfma_f32_16x16x4_f32: bit for bit an fp32 fmaf chain (what the reference's CPU path computes in).
  * OCRVI_F16X2 fp32-equivalent operands on the 16-bit matrix pipe: every GEMM operand element is stored as two fp16 halves
  *             x = hi + lo (>= 22 significant bits, weights scaled by a power of two per layer) and every product is formed from the
- *             partial products hi hi + hi lo + lo hi + lo lo in fp32 accumulators; same API, same fp32 inputs and outputs.
+ *             three partial products hi hi + hi lo + lo hi in fp32 accumulators (the lo lo term, <= 2^-22 of a product, is dropped;
+ *             conv_gemm's 64- and 32-column tiles compute all four); same API, same fp32 inputs and outputs.
+ *             Supported activation range: fp16's exponent.  An intermediate activation with |x| >= 65520 cannot be represented
+ *             (its hi half would be infinite): every kernel that writes f16x2 elements raises the handle's overflow flag instead of
+ *             passing it on silently, and ocrvi_det_status / ocrvi_rec_status report it (below).  Below |x| = 2^-3 the absolute error
+ *             of an element is 2^-25 (its lo half is a subnormal fp16 number), so tensors whose rms is under about 2^-9 lose the
+ *             fp32-equivalence (relative error 2^-25 / |x|): BatchNorm / LayerNorm keep the two models' activations at O(0.1 .. 10).
  * OCRVI_BF16 / OCRVI_F16  plain 16-bit operands (throughput modes). */
 typedef enum { OCRVI_F32 = 0, OCRVI_BF16 = 1, OCRVI_F16 = 2, OCRVI_F16X2 = 3 } ocrvi_dtype;
 

@@ -42,7 +42,9 @@ typedef _Float16 f16_t;
 // [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3]: every byte-level rule of the fp32 path (16-byte chunk = 4 channels, 128-byte K-step = 32 channels,
 // XOR swizzles, LDS-DMA pieces) holds unchanged, and an MFMA operand register quartet is (hi, lo) of 4 k-slots: with both operands in
 // that form   mfma16x16x32_f16(a, b) = sum hi_a hi_b + lo_a lo_b   and   mfma16x16x32_f16(swap(a), b) = sum lo_a hi_b + hi_a lo_b,
-// i.e. all four partial products of 16 k-steps in two instructions on the 16-bit matrix pipe (8x the fp32 MFMA rate per k-step),
+// i.e. all four partial products of 16 k-steps in two instructions on the 16-bit matrix pipe (conv_gemm's 64- and 32-column tiles use
+// this chunk form); the ring GEMM, dcn_pipe, offs_conv, attention and the wide conv_gemm tiles regroup two chunks into a hi and a lo
+// quartet and run THREE products per 32 k-steps, hi hi + hi lo + lo hi (Mma<f16x2_t>::three: lo lo <= 2^-22 of a product is dropped),
 // accumulated in fp32.  Only ever addressed in whole chunks (Chunk<f16x2_t>) or through load_elem / store_elem.
 struct f16x2_t { uint32_t raw; };
 typedef float f32x4 __attribute__((ext_vector_type(4)));

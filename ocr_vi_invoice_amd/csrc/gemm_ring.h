@@ -531,7 +531,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gemm_ring_kernel(const ConvPa
             if (dma) {
                 issue_piece(IC<0>{}); issue_piece(IC<1>{}); issue_piece(IC<2>{}); issue_piece(IC<3>{});
                 issue_piece(IC<4>{}); issue_piece(IC<5>{}); issue_piece(IC<6>{}); issue_piece(IC<7>{});
-                    }
+            }
         }
         if constexpr (IsSplit<T>::value) {
             // f16x2: both chunks of every fragment at once, regrouped into (hi, lo) quartets: three MFMAs per fragment pair (Mma<f16x2_t>)
@@ -604,10 +604,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gemm_ring_kernel(const ConvPa
                 }
             } else {
                 sgroup(IC<0>{});
-                if constexpr (MI > XB) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    sgroup(IC<XB>{});
-                }
             }
         } else {
             half(IC<0>{});

@@ -39,8 +39,13 @@ class DBNetPP:
         raises KeyError-as-RuntimeError like torch does; unexpected keys (the reference's duplicate ``backbone.layerN`` aliases, the
         unused ``fc``, optimizer state in a wrapped checkpoint) are ignored, as the reference's loader effectively does."""
         if not strict:
-            # nn.Module semantics: tensors the given dict lacks keep their current values (the initial seeded ones on a fresh model)
-            base = dict(self._state) if getattr(self, "_state", None) is not None else weights.make_det_state_dict(self._seed)
+            # nn.Module semantics: tensors the given dict lacks keep their current values.  A model built from a packed blob (the
+            # ranks behind the weight broadcast, bench.py) retains no unfolded state_dict to merge into: refuse rather than fill the
+            # missing tensors with seeded random values
+            if getattr(self, "_state", None) is None:
+                raise RuntimeError("load_state_dict(strict=False) on a model built from a packed blob: no state_dict is retained to "
+                                   "keep the missing tensors from; build the model from a state_dict, or load a complete one")
+            base = dict(self._state)
             base.update(weights.unwrap_checkpoint(state_dict))
             state_dict = base
         try:
@@ -48,7 +53,7 @@ class DBNetPP:
         except KeyError as e:
             raise RuntimeError(f"Error(s) in loading state_dict for DBNetPP: missing key {e}") from None
         self._state = {k: (v.detach().clone() if isinstance(v, torch.Tensor) else v) for k, v in weights.unwrap_checkpoint(state_dict).items()}
-        return self.load_blob(weights.pack_blob(folded))
+        return self.load_blob(weights.pack_blob(folded), _from_state=True)
 
     def state_dict(self):
         """The state_dict this model was loaded from (reference key schema); None-safe copy."""
@@ -56,7 +61,9 @@ class DBNetPP:
             raise RuntimeError("model was built from a packed blob; no state_dict is retained")
         return dict(self._state)
 
-    def load_blob(self, blob: bytes):
+    def load_blob(self, blob: bytes, _from_state: bool = False):
+        if not _from_state:
+            self._state = None      # a packed blob carries no unfolded state_dict (state_dict() / strict=False then raise)
         cfg = _lib.DetCfg()
         cfg.dtype = self.dtype
         cfg.k = self.k

@@ -12,7 +12,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 DT = {"f32": 0, "bf16": 1, "f16": 2, "f16x2": 3}
-# relative-to-output-rms budgets: f32 MFMA is an fmaf chain; f16x2 (two fp16 halves per operand, all four partial products, fp32
+# relative-to-output-rms budgets: f32 MFMA is an fmaf chain; f16x2 (two fp16 halves per operand, three partial products per product -- lo lo dropped --, fp32
 # accumulation) is held to the SAME budget as fp32; bf16 has 8 mantissa bits, fp16 11
 TOL = {"f32": 2e-5, "f16x2": 2e-5, "bf16": 4e-2, "f16": 5e-3}
 EXACT = ("f32", "f16x2")     # fp32-equivalent modes

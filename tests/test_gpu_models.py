@@ -13,7 +13,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 # Modes that must reproduce the reference's fp32 results (north_star: maps / logits within 1e-3, CTC strings identical): fp32 operands on
-# the fp32 MFMA, and f16x2 = every operand as two fp16 halves with all four partial products on the 16-bit MFMA (include/ocrvi.h).
+# the fp32 MFMA, and f16x2 = every operand as two fp16 halves with three partial products per product (hi hi + hi lo + lo hi) on the 16-bit MFMA (include/ocrvi.h).
 PARITY = ["f32", "f16x2"]
 
 
@@ -189,6 +189,31 @@ def test_module_surface_nonstrict_loading_and_device_moves():
     with pytest.raises(ValueError):
         m.to("cpu")
     assert (m.dtype, SVTRv2("tiny").dtype) == (0, 0)                                 # the default compute mode is the exact-fp32 one
+
+
+def test_nonstrict_load_on_a_blob_built_model_raises_instead_of_reseeding():
+    """A model built from a packed blob (every rank behind the weight broadcast, bench.py) retains no state_dict: a partial
+    load_state_dict(strict=False) must not silently fill the missing tensors with seeded random weights."""
+    from ocr_vi_invoice_amd import DBNetPP, SVTRv2, weights
+    sd = weights.make_rec_state_dict("tiny", seed=4)
+    m = SVTRv2("tiny", blob=weights.pack_blob(weights.fold_rec(sd, "tiny")), dtype="f32")
+    x = torch.randn(2, 3, 32, 64, generator=torch.Generator().manual_seed(1)).cuda()
+    before = m(x)
+    part = {k: v for k, v in weights.make_rec_state_dict("tiny", seed=5).items() if k.startswith("head.")}
+    with pytest.raises(RuntimeError, match="packed blob"):
+        m.load_state_dict(part, strict=False)
+    with pytest.raises(RuntimeError, match="packed blob"):
+        m.state_dict()
+    assert torch.equal(m(x), before)                                                 # the failed load left the weights alone
+    m.load_state_dict(sd)                                                            # a complete dict works and is retained from then on
+    m.load_state_dict(part, strict=False)
+    mixed = dict(sd)
+    mixed.update(part)
+    assert torch.equal(m(x), SVTRv2("tiny", state_dict=mixed, dtype="f32")(x))
+    dsd = weights.make_det_state_dict(seed=3)
+    d = DBNetPP(pretrained=False, blob=weights.pack_blob(weights.fold_det(dsd)), dtype="bf16")
+    with pytest.raises(RuntimeError, match="packed blob"):
+        d.load_state_dict({k: v for k, v in dsd.items() if k.startswith("head.")}, strict=False)
 
 
 def test_batch_limits_are_reported_not_crashed():

@@ -1,7 +1,7 @@
 """GPU: which compute mode reproduces the reference's CTC strings, at the bench workload's size.
 
-* fp32 MFMA (the parity mode, the mode bench.py quotes its headline in): strings identical to the CPU oracle on a full recogniser
-  batch of bench-like crops, and identical to the reference-run goldens.
+* fp32 MFMA and f16x2 (the parity modes; f16x2 is the mode bench.py quotes its headline in, f32 the facades' default): strings identical
+  to the CPU oracle on a full recogniser batch of bench-like crops, and identical to the reference-run goldens.
 * f16 / bf16 (throughput modes): the log-prob error is bounded by 1.5x what was measured on MI355X in round 2
   (tools/precision_study.py: f16 0.026, bf16 0.164 over 1920 bench crops), and -- the string-level statement of the same bound -- every
   time step whose fp32 top-2 margin exceeds twice that budget decodes identically.  Full string identity on the bench's crops is NOT

@@ -5,7 +5,6 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export ITERS=2
 timeout -k 10 200 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/lds -- python3 $R/tools/ring_shapes.py f16x2 > $OUT/lds.log 2>&1 || echo "lds pass failed"
-OCRVI_RING_NW4=1 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/nw4 -- python3 $R/tools/ring_shapes.py f16x2 > $OUT/nw4.log 2>&1 || echo "nw4 pass failed"
 cd $R
 python3 - <<'PY'
 import csv, glob, collections, os
@@ -18,7 +17,5 @@ for fn in f:
         agg[k][r["Counter_Name"]]+=float(r["Counter_Value"])
 for k,v in agg.items():
     if "gemm_ring" in k: print(k, {a:int(b) for a,b in v.items()})
-for fn in glob.glob(out+"/nw4/**/*kernel_stats.csv", recursive=True):
-    for r in list(csv.DictReader(open(fn)))[:6]: print(r["Name"][:90], r["Calls"], r["AverageNs"])
 PY
 find $OUT -name "*counter_collection.csv" -size +20M -delete
