@@ -25,6 +25,8 @@ extern "C" {
 #define OCRVI_EHIP (-2)   /* a HIP runtime call failed; message carries hipGetErrorString */
 #define OCRVI_ENOMEM (-3) /* workspace too small */
 #define OCRVI_EBLOB (-4)  /* weight blob malformed or a tensor is missing / has the wrong shape */
+#define OCRVI_ERANGE (-5) /* OCRVI_F16X2 only: an intermediate activation left fp16's exponent range (|x| >= 65520); reference: none -- the
+                             reference is fp32 end to end (src/pipeline/pipeline2.py:312-318), so this mode says when it cannot stand in for it */
 
 /* Arithmetic type the MFMA kernels compute in (accumulation is always fp32).
  * OCRVI_F32   fp32 operands on v_mfma_f32_16x16x4_f32: bit for bit an fp32 fmaf chain (what the reference's CPU path computes in).
@@ -74,6 +76,10 @@ int ocrvi_det_forward(ocrvi_det* h, const float* x, int N, int H, int W,
                       void* workspace, size_t workspace_bytes, void* stream);
 /* Test hook: copies of intermediate features as float32 NCHW (c2..c5 backbone.py:56-60, fused neck.py:79).
  * Any pointer may be NULL.  Must follow a forward on the same workspace and stream. */
+/* OCRVI_F16X2 handles: OCRVI_OK, or OCRVI_ERANGE when an f16x2 kernel on this handle's device has met a value fp16's exponent cannot
+ * carry since the last ocrvi_range_reset (the flag is per device and sticky; *_forward copies it to the handle asynchronously on the
+ * caller's stream, so call this AFTER synchronising that stream -- never a host sync inside *_forward).  Other dtypes: always OCRVI_OK. */
+int ocrvi_det_status(const ocrvi_det* h);
 int ocrvi_det_debug_features(ocrvi_det* h, int N, int H, int W, float* c2, float* c3, float* c4, float* c5,
                              float* fused, void* workspace, size_t workspace_bytes, void* stream);
 
@@ -110,8 +116,13 @@ int ocrvi_rec_forward(ocrvi_rec* h, const float* x, int B, int H, int W,
                       void* workspace, size_t workspace_bytes, void* stream);
 /* Test hook: float32 copies of backbone_norm output [B, H/16*W/4, D] (svtrv2.py:500) and FRM output
  * [B, W/4, D] (svtrv2.py:247).  Either may be NULL.  Must follow a forward on the same workspace/stream. */
+int ocrvi_rec_status(const ocrvi_rec* h);   /* as ocrvi_det_status */
 int ocrvi_rec_debug_features(ocrvi_rec* h, int B, int H, int W, float* backbone_norm, float* frm,
                              void* workspace, size_t workspace_bytes, void* stream);
+
+/* The per-device f16x2 range flag behind ocrvi_{det,rec}_status: reset (asynchronous on `stream`) / read (synchronises the device). */
+int ocrvi_range_reset(int device, void* stream);
+int ocrvi_range_flag(int device, int* raised);
 
 /* Standalone greedy CTC decode of caller-supplied log-probs: replaces SVTRv2.decode_probs' tensor half
  * (svtrv2.py:555-566).  log_probs [T,B,C] float32 on device. */

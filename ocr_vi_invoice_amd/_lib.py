@@ -15,7 +15,7 @@ DTYPES = {"f32": OCRVI_F32, "fp32": OCRVI_F32, "float32": OCRVI_F32, "bf16": OCR
           "f16": OCRVI_F16, "fp16": OCRVI_F16, "float16": OCRVI_F16,
           # fp32-equivalent arithmetic on the 16-bit matrix pipe: every operand kept as two fp16 halves (include/ocrvi.h)
           "f16x2": OCRVI_F16X2}
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 EXPORTS = [
     "ocrvi_last_error", "ocrvi_abi_version",
@@ -25,6 +25,7 @@ EXPORTS = [
     "ocrvi_unclip_polygon", "ocrvi_db_components_workspace_bytes", "ocrvi_db_components", "ocrvi_db_boxes_batch_sparse",
     "ocrvi_test_deform_conv", "ocrvi_test_offset_conv", "ocrvi_test_conv", "ocrvi_test_gemm", "ocrvi_test_attention", "ocrvi_test_mlp", "ocrvi_test_pack_f16x2",
     "ocrvi_prof_enable", "ocrvi_prof_reset", "ocrvi_prof_report",
+    "ocrvi_det_status", "ocrvi_rec_status", "ocrvi_range_reset", "ocrvi_range_flag",
 ]
 
 
@@ -90,6 +91,10 @@ def load() -> C.CDLL:
     lib.ocrvi_test_attention.argtypes = [i32, i32, f32p, i32, i32, i32, f32p, i32, C.POINTER(C.c_float)]
     lib.ocrvi_test_mlp.argtypes = [i32, i32, f32p, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32p, i32, C.POINTER(C.c_float)]
     lib.ocrvi_test_pack_f16x2.argtypes = [f32p, sz, vp, C.POINTER(C.c_float)]
+    lib.ocrvi_det_status.argtypes = [vp]
+    lib.ocrvi_rec_status.argtypes = [vp]
+    lib.ocrvi_range_reset.argtypes = [i32, vp]
+    lib.ocrvi_range_flag.argtypes = [i32, C.POINTER(i32)]
     lib.ocrvi_prof_enable.argtypes = [i32]
     lib.ocrvi_prof_reset.argtypes = []
     lib.ocrvi_prof_report.argtypes = [C.c_char_p, sz]
@@ -108,7 +113,8 @@ def last_error() -> str:
 
 
 def check(rc: int) -> None:
-    """0 ok; OCRVI_EINVAL -> ValueError (shape/argument), anything else -> RuntimeError."""
+    """0 ok; OCRVI_EINVAL -> ValueError (shape/argument), OCRVI_ENOMEM -> MemoryError, OCRVI_ERANGE -> OverflowError (an f16x2 activation
+    left fp16's exponent range), anything else -> RuntimeError."""
     if rc == 0:
         return
     msg = last_error()
@@ -116,6 +122,8 @@ def check(rc: int) -> None:
         raise ValueError(msg)
     if rc == -3:
         raise MemoryError(msg)
+    if rc == -5:
+        raise OverflowError(msg)
     raise RuntimeError(f"libocrvi error {rc}: {msg}")
 
 

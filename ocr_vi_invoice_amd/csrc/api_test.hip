@@ -6,6 +6,9 @@
 #include "model.h"
 
 using namespace ocrvi;
+namespace ocrvi {
+OCRVI_RANGE_FLAG_TU()   // binds this unit's f16x2 range-flag pointer (common.h)
+}
 
 namespace {
 template <typename T>
@@ -60,6 +63,8 @@ struct Scratch {
         return OCRVI_OK;
     }
     int init() {
+        unsigned* flag = nullptr;
+        OCRVI_TRY(range_flag_bind(&flag));   // the hooks run f16x2 kernels too: ocrvi_range_flag / ocrvi_range_reset see them
         OCRVI_HIP(hipStreamCreate(&s));
         OCRVI_HIP(hipEventCreate(&e0));
         OCRVI_HIP(hipEventCreate(&e1));

@@ -12,6 +12,8 @@
 #include "kernels.h"
 
 namespace ocrvi {
+OCRVI_RANGE_FLAG_TU()   // binds this unit's f16x2 range-flag pointer (common.h)
+
 
 template <typename T> struct AttnCfg;
 template <> struct AttnCfg<float> {

@@ -152,6 +152,44 @@ template <> struct Chunk<f16x2_t> {   // [4 hi | 4 lo]: u.x = (hi0, hi1), u.y = 
     }
 };
 
+// ---------------------------------------------------------------- f16x2 range flag
+// An f16x2 element is only as wide as fp16's exponent: |x| >= 65520 rounds its hi half to infinity (and the element to NaN).  Every kernel
+// that WRITES f16x2 activations tests the fp32 values it packs (two v_max + one v_cmp per 16-byte chunk; the wave's verdict is a scalar
+// mask, so the hot path has no divergent branch) and raises a per-device flag word instead of passing the value on silently; the model
+// graphs copy the word to the handle after a forward and ocrvi_{det,rec}_status report OCRVI_ERANGE (include/ocrvi.h).  The pointer to
+// the flag word is a per-translation-unit device variable, bound once per device by range_flag_bind() (host_util.hip) through the
+// binders the OCRVI_RANGE_FLAG_TU() macro registers; an unbound pointer (null) makes the check a no-op.  (In-register operands that
+// cannot leave the range of what they are built from -- attention probabilities, the deformable blend -- are packed unchecked.)
+static __device__ unsigned* g_f16x2_range_flag = nullptr;
+// wave mask of the lanes whose chunk holds a value fp16 cannot carry (an all-NaN chunk counts; a single NaN beside finite values does not:
+// v_max drops it -- NaNs only arise downstream of an infinity, which is flagged where it is produced)
+__device__ __forceinline__ unsigned long long f16x2_out_of_range(const float* f) {
+    const float m = fmaxf(fmaxf(fabsf(f[0]), fabsf(f[1])), fmaxf(fabsf(f[2]), fabsf(f[3])));
+    return __builtin_amdgcn_ballot_w64(!(m < 65520.0f));
+}
+__device__ __forceinline__ void f16x2_raise(unsigned long long mask) {
+    if (mask) {   // wave-uniform
+        unsigned* q = g_f16x2_range_flag;
+        if (q) *q = 1u;
+    }
+}
+typedef hipError_t (*RangeFlagBinder)(unsigned*);
+void range_flag_register(RangeFlagBinder fn);          // called at static-initialisation time by every translation unit with f16x2 kernels
+int range_flag_bind(unsigned** flag);                  // current device: allocates the flag word once and points every unit's variable at it
+// A handle's view of its device's flag: `snapshot` enqueues a copy of the device word into the handle's pinned host word at the end
+// of a forward (no host synchronisation); `status` is what ocrvi_{det,rec}_status return once the caller has synchronised the stream.
+struct RangeWatch {
+    unsigned* dev_word = nullptr;
+    unsigned* host_word = nullptr;   // pinned
+    int init();                      // current device
+    int snapshot(hipStream_t s);
+    int status(const char* what) const;
+    ~RangeWatch();
+};
+#define OCRVI_RANGE_FLAG_TU()                                                                                              \
+    static hipError_t range_flag_binder_(unsigned* p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_f16x2_range_flag), &p, sizeof(p)); } \
+    static struct RangeFlagReg_ { RangeFlagReg_() { ::ocrvi::range_flag_register(&range_flag_binder_); } } range_flag_reg_;
+
 // 4 consecutive T elements (16-byte aligned for fp32 / f16x2, 8-byte for the 16-bit types) <-> float[4]
 template <typename T> __device__ __forceinline__ void load4(const T* p, float* f) {
     if constexpr (IsSplit<T>::value) {
@@ -168,6 +206,7 @@ template <typename T> __device__ __forceinline__ void load4(const T* p, float* f
 }
 template <typename T> __device__ __forceinline__ void store4(T* p, const float* f) {
     if constexpr (IsSplit<T>::value) {
+        f16x2_raise(f16x2_out_of_range(f));
         *(uint4*)p = Chunk<T>::pack(f);
     } else if constexpr (sizeof(T) == 4) {
         *(float4*)p = make_float4(f[0], f[1], f[2], f[3]);
@@ -188,6 +227,7 @@ template <> __device__ __forceinline__ float load_elem<f16x2_t>(const f16x2_t* p
 template <typename T> __device__ __forceinline__ void store_elem(T* p, size_t i, float v) { p[i] = from_f32<T>(v); }
 template <> __device__ __forceinline__ void store_elem<f16x2_t>(f16x2_t* p, size_t i, float v) {
     f16_t* h = (f16_t*)(p + (i & ~(size_t)3));
+    f16x2_raise(__builtin_amdgcn_ballot_w64(!(fabsf(v) < 65520.0f)));
     const f16_t hi = (f16_t)v;
     h[i & 3] = hi;
     h[4 + (i & 3)] = (f16_t)(v - (float)hi);

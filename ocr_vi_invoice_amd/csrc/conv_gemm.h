@@ -309,8 +309,12 @@ __global__ __launch_bounds__(256, (ConvOccT<T, AMODE, BM, BN>::value)) void conv
                             const int byte = nl * osz;
                             char* dst = smem + rl * row_bytes + ((((byte >> 4) ^ rl) & (cpr - 1)) << 4) + (byte & 15);
                             if (osz == 4) {
-                                if (IsSplit<T>::value && !p.out_f32) *(uint4*)dst = Chunk<T>::pack(v);
-                                else *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+                                if (IsSplit<T>::value && !p.out_f32) {
+                                    f16x2_raise(f16x2_out_of_range(v));
+                                    *(uint4*)dst = Chunk<T>::pack(v);
+                                } else {
+                                    *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+                                }
                             } else if constexpr (sizeof(T) == 2) {
                                 union { T h[4]; uint2 u; } pk;
 #pragma unroll

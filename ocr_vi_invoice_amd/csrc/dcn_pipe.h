@@ -290,6 +290,7 @@ __global__ __launch_bounds__(512, 2) void dcn_pipe_kernel(const ConvParams p) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
                         }
+                        if constexpr (IsSplit<T>::value) f16x2_raise(f16x2_out_of_range(v));
                         *(uint4*)((T*)p.out + (size_t)m * p.ldo + p.out_coff + n) = Chunk<T>::pack(v);
                     }
                 }

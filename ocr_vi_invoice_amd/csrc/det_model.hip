@@ -30,6 +30,7 @@ struct ocrvi_det {
     ConvLayer head_conv, head_dc1;
     float* dc2_wb = nullptr;  // [2][64][4] second-deconv weights followed by the 2 biases
     Tensor tap_c[4], tap_fused;
+    RangeWatch range;     // f16x2 only: the device's range flag as of the end of the last forward
 };
 
 extern "C" int ocrvi_det_create(int device, const void* blob_p, size_t blob_bytes, const ocrvi_det_cfg* cfg, ocrvi_det** out) {
@@ -101,6 +102,7 @@ extern "C" int ocrvi_det_create(int device, const void* blob_p, size_t blob_byte
         const void* z; void* d;
         OCRVI_TRY(ring_pages(&z, &d));
     }
+    if (dt == OCRVI_F16X2) OCRVI_TRY(h->range.init());
     *out = h.release();
     return OCRVI_OK;
 }
@@ -253,7 +255,12 @@ extern "C" int ocrvi_det_forward(ocrvi_det* h, const float* x, int N, int H, int
     Runner r(h->cfg.dtype, (hipStream_t)stream, workspace, workspace_bytes);
     OCRVI_TRY(det_run(h, r, x, N, H, W, binary, thresh, thresh_binary, bin_logits, thresh_logits));
     OCRVI_CHECK(!r.arena.overflow, OCRVI_ENOMEM, "det_forward: workspace overflow");
-    return OCRVI_OK;
+    return h->range.snapshot((hipStream_t)stream);
+}
+
+extern "C" int ocrvi_det_status(const ocrvi_det* h) {
+    OCRVI_CHECK(h, OCRVI_EINVAL, "det_status: null handle");
+    return h->range.status("det");
 }
 
 extern "C" int ocrvi_det_debug_features(ocrvi_det* h, int N, int H, int W, float* c2, float* c3, float* c4, float* c5, float* fused,

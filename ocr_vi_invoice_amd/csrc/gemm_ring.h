@@ -284,6 +284,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gemm_ring_kernel(const ConvPa
 
     typedef f32x4 Acc[NI][MI];
     Acc accA, accB;
+    unsigned long long range_mask = 0;   // f16x2: lanes that packed a value fp16's exponent cannot carry (common.h)
     u32x4 res_r[SPS][4];  // residual of the group in flight: fp32 [j][a] = 4 floats; 16-bit [j][h] = 8 elements, h < 2
 
     // asm loads of slice group GRP's residual of row tile pmt: (uniform base) + 32-bit byte offset (host contract: a residual has the
@@ -384,6 +385,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gemm_ring_kernel(const ConvPa
                     const unsigned off = (row_b != OOB && nb + c < p.N_g) ? row_b + (unsigned)c * 4u : OOB;
                     u32x4 pk;
                     if (IsSplit<T>::value && !outf32) {
+                        range_mask |= f16x2_out_of_range(v);   // (scalar mask: raised once, at the end of the kernel)
                         const uint4 e = Chunk<T>::pack(v);
                         pk = (u32x4){e.x, e.y, e.z, e.w};
                     } else {
@@ -680,6 +682,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gemm_ring_kernel(const ConvPa
         if (t + 2 >= my_tiles) drain(accB, mt - Gm);
     }
     tick(3);
+    if constexpr (IsSplit<T>::value) f16x2_raise(range_mask);
     if constexpr (PROF) {
         if (lane == 0)
             for (int k = 0; k < 5; ++k) atomicAdd((unsigned long long*)p.out2 + k, (unsigned long long)tk[k]);

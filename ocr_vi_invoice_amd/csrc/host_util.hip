@@ -306,6 +306,72 @@ int ring_pages(const void** zero_page, void** dump_page) {
     return OCRVI_OK;
 }
 
+// ---- f16x2 range flag (common.h): one device word per device, every translation unit's pointer variable bound to it once
+static std::vector<RangeFlagBinder>& range_flag_binders() {
+    static std::vector<RangeFlagBinder> v;   // (function-local: filled during static initialisation of the other units)
+    return v;
+}
+void range_flag_register(RangeFlagBinder fn) { range_flag_binders().push_back(fn); }
+int range_flag_bind(unsigned** flag) {
+    static std::mutex mu;
+    static std::map<int, unsigned*> words;
+    std::lock_guard<std::mutex> lk(mu);
+    int dev = 0;
+    OCRVI_HIP(hipGetDevice(&dev));
+    auto it = words.find(dev);
+    if (it == words.end()) {
+        unsigned* w = nullptr;
+        OCRVI_HIP(hipMalloc((void**)&w, 256));
+        OCRVI_HIP(hipMemset(w, 0, 256));
+        for (RangeFlagBinder fn : range_flag_binders()) OCRVI_HIP(fn(w));
+        OCRVI_HIP(hipDeviceSynchronize());
+        it = words.emplace(dev, w).first;
+    }
+    *flag = it->second;
+    return OCRVI_OK;
+}
+
+int RangeWatch::init() {
+    OCRVI_TRY(range_flag_bind(&dev_word));
+    OCRVI_HIP(hipHostMalloc((void**)&host_word, 64, hipHostMallocDefault));
+    *host_word = 0;
+    return OCRVI_OK;
+}
+int RangeWatch::snapshot(hipStream_t s) {
+    if (!dev_word) return OCRVI_OK;
+    OCRVI_HIP(hipMemcpyAsync(host_word, dev_word, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    return OCRVI_OK;
+}
+int RangeWatch::status(const char* what) const {
+    OCRVI_CHECK(!host_word || *(volatile unsigned*)host_word == 0, OCRVI_ERANGE,
+                "%s: an f16x2 activation left fp16's range (|x| >= 65520) on this device since the last ocrvi_range_reset: the results of that "
+                "forward are not valid -- run this model with dtype f32 (or f16x2 after rescaling the offending layer)", what);
+    return OCRVI_OK;
+}
+RangeWatch::~RangeWatch() {
+    if (host_word) (void)hipHostFree(host_word);
+}
+extern "C" int ocrvi_range_reset(int device, void* stream) {
+    DeviceGuard dg(device);
+    OCRVI_HIP(dg.err);
+    unsigned* w = nullptr;
+    OCRVI_TRY(range_flag_bind(&w));
+    OCRVI_HIP(hipMemsetAsync(w, 0, sizeof(unsigned), (hipStream_t)stream));
+    return OCRVI_OK;
+}
+extern "C" int ocrvi_range_flag(int device, int* raised) {
+    OCRVI_CHECK(raised, OCRVI_EINVAL, "range_flag: null out");
+    DeviceGuard dg(device);
+    OCRVI_HIP(dg.err);
+    unsigned* w = nullptr;
+    unsigned v = 0;
+    OCRVI_TRY(range_flag_bind(&w));
+    OCRVI_HIP(hipDeviceSynchronize());
+    OCRVI_HIP(hipMemcpy(&v, w, sizeof(v), hipMemcpyDeviceToHost));
+    *raised = v != 0;
+    return OCRVI_OK;
+}
+
 int launch_conv_dt(int dtype, const ConvParams& p, int amode, hipStream_t stream) {
     char tag[160];
     double flops = 0, bytes = 0;
@@ -402,4 +468,4 @@ extern "C" int ocrvi_test_pack_f16x2(const float* src, size_t n, void* dst, floa
 }
 
 extern "C" const char* ocrvi_last_error(void) { return ocrvi::last_error_cstr(); }
-extern "C" int ocrvi_abi_version(void) { return 1; }
+extern "C" int ocrvi_abi_version(void) { return 2; }

@@ -3,6 +3,8 @@
 #include "kernels.h"
 
 namespace ocrvi {
+OCRVI_RANGE_FLAG_TU()   // binds this unit's f16x2 range-flag pointer (common.h)
+
 
 #define DISPATCH_DT(dt, CALL)                                        \
     switch (dt) {                                                    \

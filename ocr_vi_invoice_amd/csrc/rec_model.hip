@@ -41,6 +41,7 @@ struct ocrvi_rec {
     float* vq = nullptr;
     // pointers into the last forward's workspace (debug taps)
     void *tap_bn = nullptr, *tap_frm = nullptr;
+    RangeWatch range;     // f16x2 only: the device's range flag as of the end of the last forward
 };
 
 static int load_ln(DeviceStore& st, const Blob& b, const std::string& name, int d, LNw* ln) {
@@ -132,6 +133,7 @@ extern "C" int ocrvi_rec_create(int device, const void* blob_p, size_t blob_byte
         const void* z; void* d;
         OCRVI_TRY(ring_pages(&z, &d));
     }
+    if (dt == OCRVI_F16X2) OCRVI_TRY(h->range.init());
     *out = h.release();
     return OCRVI_OK;
 }
@@ -345,7 +347,12 @@ extern "C" int ocrvi_rec_forward(ocrvi_rec* h, const float* x, int B, int H, int
     Runner r(h->cfg.dtype, (hipStream_t)stream, workspace, workspace_bytes);
     OCRVI_TRY(rec_run(h, r, x, B, H, W, log_probs, argmax_ids, ids, lens));
     OCRVI_CHECK(!r.arena.overflow, OCRVI_ENOMEM, "rec_forward: workspace overflow");
-    return OCRVI_OK;
+    return h->range.snapshot((hipStream_t)stream);
+}
+
+extern "C" int ocrvi_rec_status(const ocrvi_rec* h) {
+    OCRVI_CHECK(h, OCRVI_EINVAL, "rec_status: null handle");
+    return h->range.status("rec");
 }
 
 extern "C" int ocrvi_rec_debug_features(ocrvi_rec* h, int B, int H, int W, float* backbone_norm, float* frm, void* workspace,

@@ -136,6 +136,19 @@ class DBNetPP:
 
     __call__ = forward
 
+    def check_range(self) -> None:
+        """f16x2 mode only (a no-op otherwise): synchronise the current stream and raise OverflowError if an activation left fp16's
+        exponent range (|x| >= 65520) during a forward -- the one way this mode can fail to stand in for the reference's fp32 path
+        (pipeline2.py:312-318).  ``forward`` itself never synchronises; the pipeline helpers call this where they already wait for the
+        map (``.cpu()``, pipeline2.py:320)."""
+        if self.dtype == _lib.OCRVI_F16X2:
+            torch.cuda.current_stream(self.device).synchronize()
+            _lib.check(_lib.load().ocrvi_det_status(self._handle))
+
+    def reset_range(self) -> None:
+        """Clear the device's (sticky) f16x2 range flag, e.g. after handling an OverflowError."""
+        _lib.check(_lib.load().ocrvi_range_reset(self._dev_index(), torch.cuda.current_stream(self.device).cuda_stream))
+
     def debug_features(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
         """Test hook: c2..c5 and the fused neck feature as float32 NCHW, after a forward on x."""
         x = x.to(device=self.device, dtype=torch.float32).contiguous()

@@ -351,7 +351,9 @@ def detect_and_recognize(original_image, det_model, rec_model, post_processor: D
     resized, (scale_h, scale_w) = resize_image_for_det(page, det_size)
     det_preds = det_model(normalize_for_det(resized))
     pred_binary = det_preds["binary"] if isinstance(det_preds, dict) else det_preds
-    boxes, scores = post_processor(pred_binary[0])
+    boxes, scores = post_processor(pred_binary[0])       # (copies the map to the host: the stream is synchronised from here on)
+    if hasattr(det_model, "check_range"):
+        det_model.check_range()                           # f16x2 only: OverflowError if an activation left fp16's range
     rescaled = rescale_boxes(boxes, scale_w, scale_h)
     rects = [(0,) + crop_rect((h, w), b) for b in rescaled]
     texts: List[str] = []

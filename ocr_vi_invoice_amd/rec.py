@@ -163,8 +163,21 @@ class SVTRv2:
         _lib.check(_lib.load().ocrvi_rec_debug_features(self._handle, B, H, W, bn.data_ptr(), frm.data_ptr(), ws.data_ptr(), ws.numel(), stream))
         return bn, frm
 
+    def check_range(self) -> None:
+        """f16x2 mode only (a no-op otherwise): synchronise the current stream and raise OverflowError if an activation left fp16's
+        exponent range (|x| >= 65520) during a forward.  ``forward`` never synchronises; the decode paths call this where they already
+        wait for the ids (``.tolist()``, svtrv2.py:562)."""
+        if self.dtype == _lib.OCRVI_F16X2:
+            torch.cuda.current_stream(self.device).synchronize()
+            _lib.check(_lib.load().ocrvi_rec_status(self._handle))
+
+    def reset_range(self) -> None:
+        """Clear the device's (sticky) f16x2 range flag, e.g. after handling an OverflowError."""
+        _lib.check(_lib.load().ocrvi_range_reset(self._dev_index(), torch.cuda.current_stream(self.device).cuda_stream))
+
     def _ids_to_text(self, ids: torch.Tensor, lens: torch.Tensor) -> List[str]:
         ids_h, lens_h = ids.cpu().tolist(), lens.cpu().tolist()
+        self.check_range()      # (the copies above synchronised the stream already)
         return self.tokenizer.decode([row[:n] for row, n in zip(ids_h, lens_h)])
 
     def decode_probs(self, log_probs: torch.Tensor) -> List[str]:
