@@ -54,6 +54,7 @@ struct ConvParams {
     int res_in_store = 0;  // fp32 out + fp32 residual, no activation: add the residual in the coalesced store phase
     int patch_lw = 7;      // dcn_pipe: a tile is a (128 >> patch_lw) x (1 << patch_lw) patch of output pixels
     unsigned out_bytes = 0;   // gemm_ring: bytes of the output tensor the stores may touch (buffer descriptor range; filled by launch_gemm_ring)
+    int nt_out = 0;        // gemm_ring / gemm_duo: non-temporal output stores (set by the launcher for N >= 2 K)
     float wscale = 1.f;    // f16x2: the weights are stored multiplied by 2^s (one power of two per layer, chosen by the packer so that their
                            // lo halves are normal fp16 numbers); every epilogue multiplies the accumulator by wscale = 2^-s (exact)
 };

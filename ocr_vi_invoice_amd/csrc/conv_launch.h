@@ -8,6 +8,7 @@
 
 #include "conv_gemm.h"
 #include "gemm_ring.h"
+#include "gemm_duo.h"
 #include "gconv32.h"
 #include "dcn_pipe.h"
 #include "offs_conv.h"
@@ -93,6 +94,13 @@ int launch_gemm_ring(const ConvParams& p_in, int amode, hipStream_t stream) {
     {   // range of the output buffer descriptor (gemm_ring_eligible has checked that it is below 4 GiB)
         const size_t osz = (sizeof(T) == 4 || p.out_f32) ? 4 : 2;
         p.out_bytes = (unsigned)(((size_t)(p.M - 1) * p.ldo + p.out_coff + p.N_g) * osz);
+    }
+    {   // non-temporal output stores for the 4-byte types when the output outweighs the operands (measured on the fc1 / qkv / conv3 shapes:
+        // profiles/r04_duo.md); OCRVI_RING_NT=0/1 forces it (A/B timing)
+        static const int force = getenv("OCRVI_RING_NT") ? atoi(getenv("OCRVI_RING_NT")) : -1;
+        // measured (MI355X, f16x2): K 128 N 512 244 -> 188 us, K 256 N 1024 181 -> 153, K 384 N 1152 226 -> 208, K 384 N 1536 298 -> 289;
+        // K 64 N 256 (one or two K-steps per tile, on its HBM roof) 395 -> 434 and K >= 1024 2-4 % slower: hence N >= 2 K and K >= 128
+        p.nt_out = force >= 0 ? force : ((sizeof(T) == 4 && p.N_g >= 2 * p.Kp && p.Kp >= 128) ? 1 : 0);
     }
     int n_cu = 0;
     OCRVI_TRY(device_cus(&n_cu));
@@ -216,6 +224,9 @@ int launch_conv(const ConvParams& p_in, int amode, hipStream_t stream) {
         if (gconv32_eligible(p, amode, 2)) return launch_gconv32<T>(p, stream);
     }
     if (offs_conv_eligible(p, amode, TypeInfo<T>::dtype)) return launch_offs_conv<T>(p, stream);
+    if constexpr (IsSplit<T>::value) {
+        if (gemm_duo_eligible(p, amode, TypeInfo<T>::dtype)) return launch_gemm_duo<T>(p, stream);
+    }
     if (gemm_ring_eligible(p, amode, TypeInfo<T>::dtype)) return launch_gemm_ring<T>(p, amode, stream);
     switch (amode) {
         case AM_CONV1: return launch_mode<T, AM_CONV1>(p, stream);

@@ -32,30 +32,24 @@ struct DuoPlan {
     int gm = 1;        // row-tile lanes: workgroup (lane, nt) walks 128-row tiles lane, lane + gm, ...
     int ntiles = 1;    // column tiles of BN
     int mtiles = 1;    // ceil(M / 128)
+    int nt = 0;        // non-temporal output stores
+    int dbg = 0;       // development (OCRVI_DUO_DBG, timing experiments with wrong results): 1 = every store out of range, 2 = no fragment
+                       // reads / MFMAs (the DMA stream alone), 4 = no DMA (the arithmetic alone), 8 = no barrier, 16 = no fragment reads
 };
 
 template <int N> __device__ __forceinline__ void duo_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-// s_waitcnt vmcnt(n) for a wave-uniform run-time n in {0, 2, 4} + {0, F}: the immediate must be exact (a larger one would not wait)
-template <int F> __device__ __forceinline__ void duo_wait_dyn(int na, bool stored) {
-    if (!stored) {
-        if (na == 0) duo_wait_vm<0>(); else if (na == 2) duo_wait_vm<2>(); else duo_wait_vm<4>();
-    } else {
-        if (na == 0) duo_wait_vm<F>(); else if (na == 2) duo_wait_vm<F + 2>(); else duo_wait_vm<F + 4>();
-    }
-}
-
 // RESK: 0 no residual, 1 raw fp32 residual, 2 residual in T's own format (f16x2 chunks; fp32: the same as 1).  OUTF32: raw fp32 output
-// (always for T = float).  EPI: epilogue steps of a tile (32 / EPI fragments per wave and step).
-template <typename T, int NI, int ACT, int RESK, bool OUTF32, int EPI>
+// (always for T = float).  F: fragments (= stores, = residual loads) per wave and epilogue step; a tile's epilogue takes 8 NI / F steps.
+// PROF (development, -DOCRVI_RING_PROF_BUILD + OCRVI_RING_PROF=1): shader-clock cycles per wave in the own-DMA wait / at the barrier / in MFMA
+// steps / in epilogue steps / in idle steps / in the cursor bookkeeping, added into p.out2 (uint64[8]) at exit.
+template <typename T, int NI, int ACT, int RESK, bool OUTF32, int F, bool PROF = false>
 __global__ __launch_bounds__(512, 2) void gemm_duo_kernel(const ConvParams p, const DuoPlan plan) {
     static_assert(sizeof(T) == 4, "4-byte operand types");
     static_assert(NI == 4 || NI == 3, "64 or 48 columns per wave");
-    static_assert(32 % EPI == 0, "fragments per epilogue step");
-    constexpr int MI = 8, BN = 64 * NI, BSTAGE = BN * 128, ASTAGE = 128 * 128;
-    constexpr int F = 32 / EPI;                       // fragments (= stores, = residual loads) per wave per epilogue step
-    constexpr int BPB = F / 4 > 0 ? F / 4 : 1;        // (row blocks per epilogue step when F >= 4)
-    static_assert(NI == 4 || F % NI == 0 || NI % F == 0 || true, "");
-    constexpr int FR = MI * NI;                       // fragments per wave (24 at NI = 3: the last EPI steps of a 48-column build run short)
+    constexpr int MI = 8, BN = 16 * NI * 4, BSTAGE = BN * 128, ASTAGE = 128 * 128;
+    constexpr int FR = MI * NI;                       // fragments per wave
+    static_assert(FR % F == 0 && F <= 16, "fragments per epilogue step");
+    constexpr int EPI = FR / F;                       // epilogue steps per tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     constexpr unsigned A_BASE = 2 * BSTAGE;           // A stage (g, slot) at A_BASE + (g * 3 + slot) * ASTAGE
@@ -78,79 +72,57 @@ __global__ __launch_bounds__(512, 2) void gemm_duo_kernel(const ConvParams p, co
     const int n_my = mt0 < mtiles ? (mtiles - mt0 + Gm - 1) / Gm : 0;
     const int T0 = (n_my + 1) >> 1, T1 = n_my >> 1;
     const int P = nk + EPI;                            // a group's period: nk MFMA steps, EPI epilogue steps
-    const int off1 = P >> 1;                           // group 1 runs this many steps behind group 0
+    // group 1 runs this many steps behind group 0: enough that the two groups' epilogues never coincide (each overlaps MFMA steps of the
+    // other group); no more, because group 1 idles that long at the start and group 0 at the end.  (>= 2: host contract nk >= 2, EPI >= 2)
+    const int off1 = min(EPI, P >> 1);
     const int S = max(T0 * P, T1 > 0 ? off1 + T1 * P : 0);   // steps of this workgroup
+    const int myT = grp == 0 ? T0 : T1;
 
-    // ---- DMA sources (gemm_ring.h: piece = 8 rows x 128 B, XOR swizzle on the source chunk)
+    // ---- DMA duty (gemm_ring.h: piece = 8 rows x 128 B, XOR swizzle on the source chunk).  Every wave issues, per step, NI weight pieces
+    // of step s + 1 (rows pi * 64 + wave * 8 + prow of the column tile) and -- when its OWN group runs an MFMA step at s + 2 -- four
+    // activation pieces of that step (rows (i * 4 + wn) * 8 + prow of the group's tile): a wave's issue state is its own group's
+    // execution cursor, nothing else.
     const int prow = lane >> 3;
-    const int chunk = (lane & 7) ^ swz128(wave * 8 + prow);
-    const unsigned b_off = (unsigned)((wave * 8 + prow) * ldw_b + chunk * 16);
-    const char* const b_tile = uniform_ptr((const char*)p.w + (size_t)(nt * BN) * ldw_b);
-    // issue cursor of each group's A stream: runs two steps ahead of the step counter
-    unsigned a_off[2][2];
-    const char* a_tile[2] = {nullptr, nullptr};
-    int i_pos[2] = {2, 2 - off1};                      // position in the period of step s + 2 (negative: group 1's initial delay)
-    int i_til[2] = {0, 0};                             // tile count of the group at the issue cursor
-    int i_slot[2] = {0, 0};                            // A slot the next issued stage goes to (MFMA-step count mod 3)
-    const int Tg[2] = {T0, T1};
-    auto setup_a = [&](int gg, int til) {              // per-lane source offsets of group gg's tile number til
-        const int mt = mt0 + (2 * til + gg) * Gm;
-        if (p.SH != 1 || p.SW != 1) {                  // strided 1x1 (ResNet downsample): input pixel (img, oh * SH, ow * SW)
-            a_tile[gg] = uniform_ptr(A);
+    const int chunk = (lane & 7) ^ swz128(wave * 8 + prow);      // (rows' bits 1 and 3: prow bit 1 and the wave's bit 0, for both streams)
+    unsigned b_off[NI];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int m = min(mt * 128 + (i * 8 + wave) * 8 + prow, p.M - 1);
+    for (int pi = 0; pi < NI; ++pi) b_off[pi] = (unsigned)((pi * 64 + wave * 8 + prow) * ldw_b + chunk * 16);
+    const char* const b_tile = uniform_ptr((const char*)p.w + (size_t)(nt * BN) * ldw_b);
+    unsigned a_off[4];
+    const char* a_tile = nullptr;
+    auto setup_a = [&](int til) {                      // per-lane source offsets of the group's tile number til
+        const int mt = mt0 + (2 * til + grp) * Gm;
+        if (p.SH != 1 || p.SW != 1) {                  // strided 1x1 (ResNet downsample): input pixel (img, oh * SH, ow * SW)
+            a_tile = uniform_ptr(A);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = min(mt * 128 + (i * 4 + wn) * 8 + prow, p.M - 1);
                 const int t = fastdiv(m, p.mg_ow), ow = m - t * p.OW, img = fastdiv(t, p.mg_oh), oh = t - img * p.OH;
-                a_off[gg][i] = (unsigned)((img * p.H + oh * p.SH) * p.W + ow * p.SW) * (unsigned)lda_b + chunk * 16;
+                a_off[i] = (unsigned)((img * p.H + oh * p.SH) * p.W + ow * p.SW) * (unsigned)lda_b + chunk * 16;
             }
         } else {
-            a_tile[gg] = uniform_ptr(A + (size_t)mt * 128 * lda_b);
+            a_tile = uniform_ptr(A + (size_t)mt * 128 * lda_b);
             const int last = p.M - 1 - mt * 128;       // rows past M read the last valid row (what they produce is never stored)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a_off[gg][i] = (unsigned)(min((i * 8 + wave) * 8 + prow, last) * lda_b + chunk * 16);
+            for (int i = 0; i < 4; ++i) a_off[i] = (unsigned)(min((i * 4 + wn) * 8 + prow, last) * lda_b + chunk * 16);
         }
     };
-    int i_kb = 0;                                      // weight K-step of the B stage issued next (step s + 1), and of the A stages (s + 2)
-    int i_ka = 0;
-    // DMA pieces of one step, in program order: NI weight pieces of step s + 1, then two activation pieces per group that runs an MFMA
-    // step at s + 2.  begin_issue fixes the step's constants and returns how many A pieces follow the B pieces.
-    unsigned st_bdst = 0, st_adst[2] = {0, 0};
-    const char *st_bk = nullptr, *st_ak[2] = {nullptr, nullptr};
-    bool st_a[2] = {false, false};
-    auto begin_issue = [&](int s) -> int {
-        st_bdst = lds0 + ((s + 1) & 1) * BSTAGE;
-        st_bk = b_tile + (size_t)i_kb * 128;
-        int na = 0;
-#pragma unroll
-        for (int gg = 0; gg < 2; ++gg) {
-            st_a[gg] = i_pos[gg] >= 0 && i_pos[gg] < nk && i_til[gg] < Tg[gg];
-            if (st_a[gg]) {
-                st_ak[gg] = a_tile[gg] + (size_t)i_ka * 128;
-                st_adst[gg] = lds0 + A_BASE + (gg * 3 + i_slot[gg]) * ASTAGE;
-                na += 2;
-            }
-        }
-        return na;
+    // this step's DMA constants: weight stage of step s + 1 (K-step kb1) and, if st_a, the group's activation stage of step s + 2 (ka2)
+    unsigned st_bdst = 0, st_adst = 0;
+    const char *st_bk = nullptr, *st_ak = nullptr;
+    bool st_a = false;
+    // the compiler makes no use of M0 in this kernel (checked by tools/check_ring_isa.py), so a piece sets it and leaves it
+    auto dma16 = [&](const char* sbase, unsigned voff, unsigned lds_dst) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
     };
     auto issue_piece = [&](auto PI) {
         constexpr int pi = decltype(PI)::value;
+        if (plan.dbg & 4) return;
         if constexpr (pi < NI) {
-            glds16(uniform_ptr(st_bk + (size_t)(pi * 64) * ldw_b), b_off, __builtin_amdgcn_readfirstlane(st_bdst + (pi * 8 + wave) * 1024));
+            dma16(st_bk, b_off[pi], __builtin_amdgcn_readfirstlane(st_bdst + (pi * 8 + wave) * 1024));
         } else if constexpr (pi < NI + 4) {
-            constexpr int gg = (pi - NI) >> 1, i = (pi - NI) & 1;
-            if (st_a[gg]) glds16(uniform_ptr(st_ak[gg]), a_off[gg][i], __builtin_amdgcn_readfirstlane(st_adst[gg] + (i * 8 + wave) * 1024));
-        }
-    };
-    auto end_issue = [&]() {
-        if (++i_kb == nk) i_kb = 0;
-        if (++i_ka == nk) i_ka = 0;
-#pragma unroll
-        for (int gg = 0; gg < 2; ++gg) {
-            if (st_a[gg] && ++i_slot[gg] == 3) i_slot[gg] = 0;
-            if (++i_pos[gg] == P) {
-                i_pos[gg] = 0;
-                if (++i_til[gg] < Tg[gg]) setup_a(gg, i_til[gg]);
-            }
+            constexpr int i = pi - NI;
+            if (st_a) dma16(st_ak, a_off[i], __builtin_amdgcn_readfirstlane(st_adst + (i * 4 + wn) * 1024));
         }
     };
     auto issue_all = [&]() {
@@ -190,16 +162,19 @@ __global__ __launch_bounds__(512, 2) void gemm_duo_kernel(const ConvParams p, co
     unsigned long long range_mask = 0;
 
     // ---- execution cursor of this wave's group
-    int e_pos = grp == 0 ? 0 : -off1;                  // position in the period of step s
-    int e_til = 0;
+    int e_pos = grp == 0 ? 0 : -off1;                  // position in the period of step s (negative: group 1's initial delay)
+    int e_til = 0;                                     // tiles the group has finished
     int e_slot = 0;                                    // A slot of the group's next MFMA step
-    const int myT = grp == 0 ? T0 : T1;
 
     // one MFMA step: all NI weight fragments up front, the eight row blocks streamed one ahead; DMA piece b rides behind row block b
     auto mfma_step = [&](const char* As, const char* Bs) {
         const char* Br = Bs + (wn * (16 * NI) + lr) * 128;
         const char* Ar = As + lr * 128;
         if constexpr (IsSplit<T>::value) {
+            // Fixed schedule (pinned with sched_barrier between every pair of MFMAs): a row block is 3 NI MFMAs = three products x NI column
+            // blocks; the other work of the block -- the two fragment reads of row block b + 2, the regrouping of row block b + 1 into its
+            // (hi, lo) quartets (a second register set) and one DMA piece -- sits BETWEEN MFMA pairs, so that a wave that has the SIMD's
+            // matrix pipe to itself (its partner is in an epilogue step) still feeds it back to back instead of pausing at block borders.
             typedef typename Mma<T>::u4v U;
             uint4 wc[NI][2], xc[2][2];
 #pragma unroll
@@ -209,26 +184,51 @@ __global__ __launch_bounds__(512, 2) void gemm_duo_kernel(const ConvParams p, co
             }
             xc[0][0] = lds16(Ar + foa0);
             xc[0][1] = lds16(Ar + foa1);
+            xc[1][0] = lds16(Ar + 2048 + foa0);
+            xc[1][1] = lds16(Ar + 2048 + foa1);
             __builtin_amdgcn_sched_barrier(0);
-            U wH[NI], wL[NI];
+            U wH[NI], wL[NI], xH[2], xL[2];
 #pragma unroll
             for (int a = 0; a < NI; ++a) Mma<T>::regroup(wc[a][0], wc[a][1], wH[a], wL[a]);
+            Mma<T>::regroup(xc[0][0], xc[0][1], xH[0], xL[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            auto mm = [&](const U& w, const U& x, f32x4& c) {
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), c, 0, 0, 0);
+            };
             auto blk = [&](auto BB) {
-                constexpr int b = decltype(BB)::value;
-                if constexpr (b + 1 < MI) {
-                    xc[(b + 1) & 1][0] = lds16(Ar + (b + 1) * 2048 + foa0);
-                    xc[(b + 1) & 1][1] = lds16(Ar + (b + 1) * 2048 + foa1);
-                }
-                U xH, xL;
-                Mma<T>::regroup(xc[b & 1][0], xc[b & 1][1], xH, xL);
+                constexpr int b = decltype(BB)::value, cur = b & 1, nxt = cur ^ 1;
+                // products: wL.xH, wH.xL, wH.xH (Mma<f16x2_t>::three), column blocks in pairs
+                mm(wL[0], xH[cur], acc[0][b]); mm(wL[1], xH[cur], acc[1][b]);
+                if constexpr (b + 2 < MI) xc[cur][0] = lds16(Ar + (b + 2) * 2048 + foa0);     // (xc[cur] was regrouped during block b - 1)
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int a = 0; a < NI; ++a) Mma<T>::three(wH[a], wL[a], xH, xL, acc[a][b]);
+                mm(wL[2], xH[cur], acc[2][b]);
+                if constexpr (NI == 4) mm(wL[3], xH[cur], acc[3][b]);
+                if constexpr (b + 2 < MI) xc[cur][1] = lds16(Ar + (b + 2) * 2048 + foa1);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(wH[0], xL[cur], acc[0][b]); mm(wH[1], xL[cur], acc[1][b]);
+                if constexpr (b + 1 < MI) xH[nxt] = (U){xc[nxt][0].x, xc[nxt][0].y, xc[nxt][1].x, xc[nxt][1].y};
+                __builtin_amdgcn_sched_barrier(0);
+                mm(wH[2], xL[cur], acc[2][b]);
+                if constexpr (NI == 4) mm(wH[3], xL[cur], acc[3][b]);
+                if constexpr (b + 1 < MI) xL[nxt] = (U){xc[nxt][0].z, xc[nxt][0].w, xc[nxt][1].z, xc[nxt][1].w};
+                __builtin_amdgcn_sched_barrier(0);
+                mm(wH[0], xH[cur], acc[0][b]); mm(wH[1], xH[cur], acc[1][b]);
                 __builtin_amdgcn_sched_barrier(0);
                 issue_piece(IC<b>{});
                 __builtin_amdgcn_sched_barrier(0);
+                mm(wH[2], xH[cur], acc[2][b]);
+                if constexpr (NI == 4) mm(wH[3], xH[cur], acc[3][b]);
+                __builtin_amdgcn_sched_barrier(0);
             };
-            blk(IC<0>{}); blk(IC<1>{}); blk(IC<2>{}); blk(IC<3>{}); blk(IC<4>{}); blk(IC<5>{}); blk(IC<6>{}); blk(IC<7>{});
+            // Issue priority: the two waves of a SIMD are in different groups.  With equal priority the older wave wins every arbitration, runs
+            // its step at full speed and then waits at the barrier while the younger one works through its step alone, gaps unfilled.  Group 0
+            // takes priority in the first half of a step and group 1 in the second, so both progress side by side and fill each other's gaps.
+            const bool flip = !(plan.dbg & 64);
+            if (flip) { if (grp == 0) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); }
+            blk(IC<0>{}); blk(IC<1>{}); blk(IC<2>{}); blk(IC<3>{});
+            if (flip) { if (grp == 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2); }
+            blk(IC<4>{}); blk(IC<5>{}); blk(IC<6>{}); blk(IC<7>{});
+            if (flip) __builtin_amdgcn_s_setprio(0);
         } else {
             uint4 wf[NI][2], xf[2][2];
 #pragma unroll
@@ -285,7 +285,8 @@ __global__ __launch_bounds__(512, 2) void gemm_duo_kernel(const ConvParams p, co
         }
         if (!(RESK != 0 && p.res_post)) activate(v);
         const int m = mt * 128 + b * 16 + lr, cn = 16 * a + 4 * g;
-        const unsigned off = (m < p.M && nb + cn < p.N_g) ? ((unsigned)m * (unsigned)p.ldo + (unsigned)(p.out_coff + nb + cn)) * 4u : OOB;
+        unsigned off = (m < p.M && nb + cn < p.N_g) ? ((unsigned)m * (unsigned)p.ldo + (unsigned)(p.out_coff + nb + cn)) * 4u : OOB;
+        if (plan.dbg & 1) off = OOB;
         u32x4 pk;
         if constexpr (IsSplit<T>::value && !OUTF32) {
             range_mask |= f16x2_out_of_range(v);
@@ -294,12 +295,24 @@ __global__ __launch_bounds__(512, 2) void gemm_duo_kernel(const ConvParams p, co
         } else {
             pk = (u32x4){__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
         }
-        __builtin_amdgcn_raw_buffer_store_b128(pk, orsrc, off, 0, 0);
+        // nt: the output of a GEMM with N >= 2 K outweighs what it reads; written with the default policy its lines push the activation
+        // rows the other column tiles still want out of the XCD's L2 (measured: 292 -> 256 us at K = 256, N = 1024; 254 -> 279 us at K = 1536)
+        if (plan.nt) __builtin_amdgcn_raw_buffer_store_b128(pk, orsrc, off, 0, 2);
+        else __builtin_amdgcn_raw_buffer_store_b128(pk, orsrc, off, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     };
-    // epilogue step E0 of the group's finished tile: residual loads, this step's DMA pieces, then F fragments.  Returns with exactly
-    // F stores issued after the DMA pieces (a step of a 48-column build that has run out of fragments pads with out-of-range stores).
-    auto epi_step = [&](auto EE, int mt, int na) {
+    // epilogue step e of the group's finished tile: residual loads, this step's DMA pieces, then F fragments.  Exactly F stores follow the
+    // DMA pieces (out-of-range lanes are dropped by the buffer descriptor's range check, the instruction still issues).
+    long long* tkp = nullptr;   // (PROF: the loop's stamp state, so that the epilogue can split its own time)
+    long long* t0p = nullptr;
+    auto etick = [&](int k) {
+        if constexpr (PROF) {
+            const long long t = clock64();
+            tkp[k] += t - *t0p;
+            *t0p = t;
+        }
+    };
+    auto epi_step = [&](auto EE, int mt) {
         constexpr int e = decltype(EE)::value;
         auto each = [&](auto fn) {
             if constexpr (F >= 1) fn(IC<0>{});
@@ -312,75 +325,84 @@ __global__ __launch_bounds__(512, 2) void gemm_duo_kernel(const ConvParams p, co
         if constexpr (RESK != 0) {
             each([&](auto J) {
                 constexpr int j = decltype(J)::value, f = e * F + j;
-                if constexpr (f < FR) gload16s(res_r[j], res_base, res_off(mt, f / NI, f % NI));
-                else gload16s(res_r[j], res_base, 0u);
+                gload16s(res_r[j], res_base, res_off(mt, f / NI, f % NI));
             });
         }
+        etick(6);
         issue_all();
-        if constexpr (RESK != 0) {   // the residual loads are older than this step's NI + na DMA pieces only
-            if (na == 0) duo_wait_vm<NI>(); else if (na == 2) duo_wait_vm<NI + 2>(); else duo_wait_vm<NI + 4>();
+        etick(7);
+        if constexpr (RESK != 0) {   // the residual loads are older than this step's NI (+ 4) DMA pieces only
+            if (st_a) duo_wait_vm<NI + 4>(); else duo_wait_vm<NI>();
             each([&](auto J) { bind16(res_r[decltype(J)::value]); });
         }
         each([&](auto J) {
             constexpr int j = decltype(J)::value, f = e * F + j;
-            if constexpr (f < FR) {
-                epi_frag(mt, IC<f>{}, J);
-            } else {
-                __builtin_amdgcn_raw_buffer_store_b128((u32x4){0u, 0u, 0u, 0u}, orsrc, OOB, 0, 0);
-            }
+            epi_frag(mt, IC<f>{}, J);
         });
     };
 
-    // ---- prologue: weight step 0, activation steps 0 and 1 of whichever group starts there
-    if (n_my > 0) {
-        setup_a(0, 0);
-        if (T1 > 0) setup_a(1, 0);
-    }
-    int last_na = 0;
-    bool last_stored = false;
+    // ---- prologue: the weight stage of step 0 (all waves) and the activation stages of steps 0 and 1 of group 0 (its waves; group 1's first
+    // tile starts off1 >= 2 steps later and is issued from the loop)
+    int kb = 0, kb1 = nk > 1 ? 1 : 0, ka2 = nk > 2 ? 2 : (2 % nk);   // K-step of step s / s + 1 / s + 2
+    bool last_a = false, last_stored = false;
     if (S > 0) {
-        // (the generic issue path is driven with fake step numbers: B(0) goes to slot 0 as "step -1", A for steps 0 and 1 as "steps -2, -1")
-        i_pos[0] = 0; i_pos[1] = -off1;
-        {   // A stages of step 0
-            st_bdst = lds0; st_bk = b_tile;
-#pragma unroll
-            for (int gg = 0; gg < 2; ++gg) {
-                st_a[gg] = i_pos[gg] >= 0 && i_pos[gg] < nk && i_til[gg] < Tg[gg];
-                st_ak[gg] = a_tile[gg];
-                st_adst[gg] = lds0 + A_BASE + (gg * 3 + i_slot[gg]) * ASTAGE;
-            }
+        if (myT > 0) setup_a(0);
+        st_bdst = lds0; st_bk = b_tile;
+        issue_piece(IC<0>{}); issue_piece(IC<1>{}); issue_piece(IC<2>{});
+        if constexpr (NI == 4) issue_piece(IC<3>{});
+        if (grp == 0) {
+            st_a = true;
+            st_ak = a_tile; st_adst = lds0 + A_BASE;
             issue_piece(IC<NI>{}); issue_piece(IC<NI + 1>{}); issue_piece(IC<NI + 2>{}); issue_piece(IC<NI + 3>{});
-            // B of step 0 (its K-step counter advances here; the A cursor's in end_issue below)
-            issue_piece(IC<0>{}); issue_piece(IC<1>{}); issue_piece(IC<2>{});
-            if constexpr (NI == 4) issue_piece(IC<3>{});
-            const int kb_keep = i_kb;
-            end_issue();               // A cursor -> step 1; (i_kb advanced to 1: B(1) is what step 0 issues)
-            (void)kb_keep;
-        }
-        {   // A stages of step 1
-            const int kb_keep = i_kb;
-#pragma unroll
-            for (int gg = 0; gg < 2; ++gg) {
-                st_a[gg] = i_pos[gg] >= 0 && i_pos[gg] < nk && i_til[gg] < Tg[gg];
-                if (st_a[gg]) {
-                    st_ak[gg] = a_tile[gg] + (size_t)i_ka * 128;
-                    st_adst[gg] = lds0 + A_BASE + (gg * 3 + i_slot[gg]) * ASTAGE;
-                }
-            }
-            last_na = (st_a[0] ? 2 : 0) + (st_a[1] ? 2 : 0);
+            st_ak = uniform_ptr(a_tile + (size_t)kb1 * 128); st_adst = lds0 + A_BASE + ASTAGE;
             issue_piece(IC<NI>{}); issue_piece(IC<NI + 1>{}); issue_piece(IC<NI + 2>{}); issue_piece(IC<NI + 3>{});
-            end_issue();
-            i_kb = kb_keep;            // the prologue issued B(0) only
+            last_a = true;   // (the wait of step 0 may leave the four pieces of step 1 in flight)
         }
     }
 
+    long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;
+    auto tick = [&](int k) {
+        if constexpr (PROF) {
+            const long long t = clock64();
+            tk[k] += t - t0;
+            t0 = t;
+        }
+    };
+    if constexpr (PROF) t0 = clock64();
+    tkp = tk; t0p = &t0;
     for (int s = 0; s < S; ++s) {
-        // stage s has landed: everything this wave issued up to B(s)'s pieces (what may still fly: the A pieces and the stores behind them)
-        duo_wait_dyn<F>(last_na, last_stored);
-        asm volatile("s_barrier" ::: "memory");
-        const int na = begin_issue(s);
-        const bool mf = e_pos >= 0 && e_pos < nk && e_til < myT;
-        const bool ep = e_pos >= nk && e_til < myT;
+        // stage s has landed: everything this wave issued up to the weight pieces of step s (what may still fly: its four activation
+        // pieces of step s + 1 and the stores behind them)
+        if (!last_stored) {
+            if (last_a) duo_wait_vm<4>(); else duo_wait_vm<0>();
+        } else {
+            if (last_a) duo_wait_vm<F + 4>(); else duo_wait_vm<F>();
+        }
+        tick(0);
+        if (!(plan.dbg & 8)) asm volatile("s_barrier" ::: "memory");
+        tick(1);
+        const bool live = e_til < myT;
+        const bool mf = live && e_pos >= 0 && e_pos < nk;
+        const bool ep = live && e_pos >= nk;
+        const int e = e_pos - nk;
+        // DMA plan of the step
+        st_bdst = lds0 + ((s + 1) & 1) * BSTAGE;
+        st_bk = uniform_ptr(b_tile + (size_t)kb1 * 128);
+        int aslot = -1;                                 // A slot the group's stage of step s + 2 goes to (-1: none)
+        if (mf) {
+            if (e_pos + 2 < nk) aslot = e_slot + 2;
+        } else if (ep) {
+            if (e == 0 && e_til + 1 < myT) setup_a(e_til + 1);           // (the finished tile's last activation stage was issued two steps ago)
+            if (e >= EPI - 2 && e_til + 1 < myT) aslot = e_slot + (e - (EPI - 2));
+        } else if (live && e_pos >= -2) {
+            aslot = e_pos + 2;                          // group 1's first tile: its steps 0 and 1
+        }
+        st_a = aslot >= 0;
+        if (st_a) {
+            if (aslot >= 3) aslot -= 3;
+            st_ak = uniform_ptr(a_tile + (size_t)ka2 * 128);
+            st_adst = lds0 + A_BASE + (grp * 3 + aslot) * ASTAGE;
+        }
         const int mt = mt0 + (2 * e_til + grp) * Gm;
         if (mf) {
             if (e_pos == 0) {
@@ -389,44 +411,64 @@ __global__ __launch_bounds__(512, 2) void gemm_duo_kernel(const ConvParams p, co
 #pragma unroll
                     for (int b = 0; b < MI; ++b) acc[a][b] = bias_r[a];
             }
-            mfma_step(smem + A_BASE + (grp * 3 + e_slot) * ASTAGE, smem + (s & 1) * BSTAGE);
+            if (plan.dbg & 2) issue_all();
+            else mfma_step(smem + A_BASE + (grp * 3 + e_slot) * ASTAGE, smem + (s & 1) * BSTAGE);
             if (++e_slot == 3) e_slot = 0;
             last_stored = false;
+            tick(2);
         } else if (ep) {
-            const int e = e_pos - nk;
             bool done = false;
             auto pick = [&](auto EE) {
                 if (!done && e == decltype(EE)::value) {
-                    epi_step(EE, mt, na);
+                    epi_step(EE, mt);
                     done = true;
                 }
             };
-            if constexpr (EPI >= 1) pick(IC<0>{});
-            if constexpr (EPI >= 2) pick(IC<1>{});
-            if constexpr (EPI >= 4) { pick(IC<2>{}); pick(IC<3>{}); }
-            if constexpr (EPI >= 8) { pick(IC<4>{}); pick(IC<5>{}); pick(IC<6>{}); pick(IC<7>{}); }
-            if constexpr (EPI >= 16) { pick(IC<8>{}); pick(IC<9>{}); pick(IC<10>{}); pick(IC<11>{}); pick(IC<12>{}); pick(IC<13>{}); pick(IC<14>{}); pick(IC<15>{}); }
-            if constexpr (EPI >= 32) {
-                pick(IC<16>{}); pick(IC<17>{}); pick(IC<18>{}); pick(IC<19>{}); pick(IC<20>{}); pick(IC<21>{}); pick(IC<22>{}); pick(IC<23>{});
-                pick(IC<24>{}); pick(IC<25>{}); pick(IC<26>{}); pick(IC<27>{}); pick(IC<28>{}); pick(IC<29>{}); pick(IC<30>{}); pick(IC<31>{});
-            }
+            if constexpr (EPI > 0) pick(IC<0>{});
+            if constexpr (EPI > 1) pick(IC<1>{});
+            if constexpr (EPI > 2) pick(IC<2>{});
+            if constexpr (EPI > 3) pick(IC<3>{});
+            if constexpr (EPI > 4) pick(IC<4>{});
+            if constexpr (EPI > 5) pick(IC<5>{});
+            if constexpr (EPI > 6) pick(IC<6>{});
+            if constexpr (EPI > 7) pick(IC<7>{});
+            if constexpr (EPI > 8) pick(IC<8>{});
+            if constexpr (EPI > 9) pick(IC<9>{});
+            if constexpr (EPI > 10) pick(IC<10>{});
+            if constexpr (EPI > 11) pick(IC<11>{});
+            if constexpr (EPI > 12) pick(IC<12>{});
+            if constexpr (EPI > 13) pick(IC<13>{});
+            if constexpr (EPI > 14) pick(IC<14>{});
+            if constexpr (EPI > 15) pick(IC<15>{});
+            static_assert(EPI <= 16, "more epilogue steps than the dispatch chain covers");
             last_stored = true;
+            tick(3);
         } else {
-            issue_all();       // idle (group 1 before its first tile, a group after its last): the DMA duty stays
+            issue_all();       // idle (group 1 before its first tile, a group after its last): the weight DMA duty stays
             last_stored = false;
+            tick(4);
         }
-        end_issue();
-        last_na = na;
+        last_a = st_a;
+        kb = kb1; kb1 = ka2;
+        if (++ka2 == nk) ka2 = 0;
         if (++e_pos == P) {
             e_pos = 0;
             ++e_til;
         }
+        tick(5);
+    }
+    if constexpr (PROF) {
+        if (lane == 0)
+            for (int k = 0; k < 8; ++k) atomicAdd((unsigned long long*)p.out2 + grp * 8 + k, (unsigned long long)tk[k]);
     }
     duo_wait_vm<0>();          // no DMA may land in LDS after the workgroup has gone
     if constexpr (IsSplit<T>::value && !OUTF32) f16x2_raise(range_mask);
 }
 
 template <typename T> int launch_gemm_duo(const ConvParams& p, hipStream_t stream);
+template <> int launch_gemm_duo<f16x2_t>(const ConvParams& p, hipStream_t stream);   // duo_f16x2.hip
+// column tile for Np output columns: 256 (64 per wave) when it divides, else 192 (48 per wave), else 0 = not a duo shape
+static inline int duo_bn_for(int Np) { return Np % 256 == 0 ? 256 : (Np % 192 == 0 ? 192 : 0); }
 // true when p is a GEMM the duo kernel is built for (and faster at than gemm_ring)
 bool gemm_duo_eligible(const ConvParams& p, int amode, int dtype);
 

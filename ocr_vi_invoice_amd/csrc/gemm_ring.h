@@ -391,7 +391,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gemm_ring_kernel(const ConvPa
                     } else {
                         pk = (u32x4){__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
                     }
-                    __builtin_amdgcn_raw_buffer_store_b128(pk, orsrc, off, 0, 0);
+                    // (nt: an output that outweighs the operands -- N >= 2 K -- written with the default policy pushes the activation rows the other
+                    // column tiles still want out of the XCD's L2; launch_gemm_ring sets the flag)
+                    if (p.nt_out) __builtin_amdgcn_raw_buffer_store_b128(pk, orsrc, off, 0, 2);
+                    else __builtin_amdgcn_raw_buffer_store_b128(pk, orsrc, off, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else {

@@ -11,6 +11,7 @@
 
 #include "conv_gemm.h"
 #include "gemm_ring.h"
+#include "gemm_duo.h"
 #include "dcn_pipe.h"
 
 namespace ocrvi {
@@ -257,6 +258,30 @@ bool gemm_ring_eligible(const ConvParams& p, int amode, int dtype) {
     return true;
 }
 
+// The duo ring GEMM (gemm_duo.h): f16x2 1x1 convolutions / Linears that gemm_ring would take, whose column count tiles by 256 or 192,
+// with at least four K-steps (below that the layers sit on their HBM roof in either kernel) and an epilogue variant that is built
+// (duo_f16x2.hip: launch_duo_ni).  The choice depends on the layer only (N, K, epilogue), never on M, so a page alone and the same page
+// inside a batch take the same kernel.  OFF by default (OCRVI_GEMM_DUO=1 enables it, read once per process): measured end to end it
+// ties gemm_ring (260.1 vs 260.5 invoices/s) -- 12-20 % faster at K <= 384 with N >= 1024 and no GELU, equal at long K, slower with GELU;
+// why (a wave alone on its SIMD drives the matrix pipe at about half the rate two waves reach together, so the "solo" MFMA steps beside
+// the other group's epilogue are no shorter than shared ones) is measured in profiles/r04_duo.md with tools/mfma_mix.hip.
+bool gemm_duo_eligible(const ConvParams& p, int amode, int dtype) {
+    static const bool on = getenv("OCRVI_GEMM_DUO") && atoi(getenv("OCRVI_GEMM_DUO")) != 0;
+    if (!on || dtype != OCRVI_F16X2 || amode != AM_CONV1) return false;
+    if (!gemm_ring_eligible(p, amode, dtype)) return false;
+    static const int min_nk = getenv("OCRVI_DUO_MIN_NK") ? atoi(getenv("OCRVI_DUO_MIN_NK")) : 4;
+    if (duo_bn_for(p.Np) == 0 || p.Kp / 32 < min_nk) return false;
+    const int resk = p.res_mode == RES_NONE ? 0 : (p.res_f32 ? 1 : 2);
+    const bool of32 = p.out_f32 != 0;
+    // (GELU epilogues stay on gemm_ring: ~80 VALU instructions per fragment spread over the next tile's MFMA steps by the same wave beat
+    // epilogue steps beside the other group's MFMAs -- 326 vs 390 us at M 61440, K 384, N 1536; OCRVI_DUO_GELU=1 routes them here anyway)
+    static const bool gelu = getenv("OCRVI_DUO_GELU") && atoi(getenv("OCRVI_DUO_GELU"));
+    if (p.act == ACT_GELU && !gelu) return false;
+    if (resk == 0) return of32 ? p.act == ACT_NONE : true;
+    if (resk == 2) return !of32 && p.act != ACT_GELU;
+    return of32 && p.act == ACT_NONE;     // raw fp32 residual stream: fp32 output
+}
+
 int device_cus(int* n_cu) {
     static std::mutex mu;
     static std::map<int, int> cus;
@@ -390,7 +415,10 @@ int launch_conv_dt(int dtype, const ConvParams& p, int amode, hipStream_t stream
         const bool ring = gemm_ring_eligible(q, amode, dtype);
         const bool pipe = amode == AM_DCN && dcn_pipe_eligible(q, dtype);
         static const bool detail = getenv("OCRVI_PROF_DETAIL") != nullptr;
-        if (ring && !detail)
+        const bool duo = gemm_duo_eligible(q, amode, dtype);
+        if (duo && !detail)
+            snprintf(tag, sizeof(tag), "gemm_duo_%s", dtype_name(dtype));
+        else if (ring && !detail)
             snprintf(tag, sizeof(tag), "gemm_ring_%s", dtype_name(dtype));
         else if (pipe && !detail)
             snprintf(tag, sizeof(tag), "dcn3x3_pipe128x%d_%s", p.Np % 256 == 0 ? 256 : 128, dtype_name(dtype));

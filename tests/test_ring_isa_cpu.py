@@ -36,3 +36,16 @@ def test_no_mfma_kernel_of_the_library_spills(src):
     bad = {n: v for n, v in rep.items() if v[0] != 0}
     assert not bad, f"kernels with scratch instructions: {bad}"
     assert all(v[1] > 0 for v in rep.values())
+
+
+@pytest.mark.skipif(not shutil.which("/opt/rocm/bin/hipcc"), reason="hipcc not available")
+def test_duo_gemm_isa_keeps_its_protocol():
+    """gemm_duo.h counts vmcnt by hand like the ring and sets M0 without saving it: no scratch, no compiler vmcnt wait inside the pipeline,
+    no compiler use of M0."""
+    import check_ring_isa
+    rep = check_ring_isa.check_duo()
+    assert len(rep) >= 12
+    for name, r in rep.items():
+        assert r["mfma"] > 0 and r["scratch"] == 0, (name, r["scratch"])
+        assert len(r["compiler_vmcnt_waits"]) <= 1, (name, r["compiler_vmcnt_waits"])
+        assert not r["m0_uses"], (name, r["m0_uses"][:3])

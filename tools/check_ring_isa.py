@@ -61,7 +61,7 @@ def touches_before_wait(body, start, dst):
     return hits
 
 
-ALL_SOURCES = ["conv_bf16.hip", "conv_f16.hip", "conv_f32.hip", "conv_f16x2.hip", "mlp_fused.hip", "attention.hip"]
+ALL_SOURCES = ["conv_bf16.hip", "conv_f16.hip", "conv_f32.hip", "conv_f16x2.hip", "duo_f16x2.hip", "mlp_fused.hip", "attention.hip"]
 _ASM = {}
 
 
@@ -118,6 +118,18 @@ def check(src):
 # uncounted VMEM operation in a hand-counted vmcnt protocol; anywhere else it is a performance bug).
 OTHER_KERNELS = ["_ZN5ocrvi15dcn_pipe_kernel", "_ZN5ocrvi16offs_conv_kernel", "_ZN5ocrvi16mlp_fused_kernel", "_ZN5ocrvi16conv_gemm_kernel",
                  "_ZN5ocrvi14gconv32_kernel", "_ZN5ocrvi16attention_kernel", "_ZN5ocrvi18attention16_kernel"]
+
+
+def check_duo(src="duo_f16x2.hip"):
+    """The duo ring GEMM (gemm_duo.h): per kernel -- scratch instructions (must be 0), compiler-inserted vmcnt waits before the last inline-asm
+    statement (at most the one behind the bias loads), and uses of M0 outside inline asm (must be 0: a DMA piece sets M0 and leaves it)."""
+    rep = {}
+    for name, body in kernel_bodies(asm_of(src), "_ZN5ocrvi15gemm_duo_kernel").items():
+        last_asm = max((i for i, (t, a) in enumerate(body) if a), default=len(body))
+        rep[name] = dict(scratch=sum("scratch_" in t for t, _ in body), mfma=sum("v_mfma" in t for t, _ in body),
+                         compiler_vmcnt_waits=[t for i, (t, a) in enumerate(body) if not a and i < last_asm and t.startswith("s_waitcnt") and "vmcnt" in t],
+                         m0_uses=[t for t, a in body if not a and re.search(r"\bm0\b", t)])
+    return rep
 
 
 def check_scratch(src):
