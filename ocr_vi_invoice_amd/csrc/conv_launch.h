@@ -95,12 +95,13 @@ int launch_gemm_ring(const ConvParams& p_in, int amode, hipStream_t stream) {
         const size_t osz = (sizeof(T) == 4 || p.out_f32) ? 4 : 2;
         p.out_bytes = (unsigned)(((size_t)(p.M - 1) * p.ldo + p.out_coff + p.N_g) * osz);
     }
-    {   // non-temporal output stores for the 4-byte types when the output outweighs the operands (measured on the fc1 / qkv / conv3 shapes:
-        // profiles/r04_duo.md); OCRVI_RING_NT=0/1 forces it (A/B timing)
-        static const int force = getenv("OCRVI_RING_NT") ? atoi(getenv("OCRVI_RING_NT")) : -1;
-        // measured (MI355X, f16x2): K 128 N 512 244 -> 188 us, K 256 N 1024 181 -> 153, K 384 N 1152 226 -> 208, K 384 N 1536 298 -> 289;
-        // K 64 N 256 (one or two K-steps per tile, on its HBM roof) 395 -> 434 and K >= 1024 2-4 % slower: hence N >= 2 K and K >= 128
-        p.nt_out = force >= 0 ? force : ((sizeof(T) == 4 && p.N_g >= 2 * p.Kp && p.Kp >= 128) ? 1 : 0);
+    {   // non-temporal output stores (OCRVI_RING_NT=1; off by default).  Alone on the chip a GEMM whose output outweighs its operands
+        // (N >= 2 K) runs 3-23 % faster with them (K 128 N 512 244 -> 188 us, K 256 N 1024 181 -> 153, K 384 N 1152 226 -> 208: the output
+        // no longer displaces the activation rows the other column tiles want from L2) -- but inside the models the next layer then
+        // misses what it would have found in L2 / the Infinity Cache, and the ring total of a bench step does not move (131.8 vs 131.7 ms;
+        // profiles/r04_duo.md section 3)
+        static const int force = getenv("OCRVI_RING_NT") ? atoi(getenv("OCRVI_RING_NT")) : 0;
+        p.nt_out = (force == 1 && sizeof(T) == 4 && p.N_g >= 2 * p.Kp && p.Kp >= 128) ? 1 : (force == 2 ? 1 : 0);
     }
     int n_cu = 0;
     OCRVI_TRY(device_cus(&n_cu));
