@@ -68,6 +68,13 @@ def parse():
                     help="DB post-processing: host = D2H of the whole map, everything on the host (as the reference); device = threshold + "
                          "component labelling + box packing on the GPU, only mask / table / box values cross PCIe, host finishes")
     ap.add_argument("--post-threads", type=int, default=0, help="host threads for DB post-processing (0 = cores available / ranks, at most 16)")
+    ap.add_argument("--balance", choices=["static", "queue"], default="static",
+                    help="static: every rank walks its own contiguous shard of pages (the contract's weak-scaling run).  queue: every rank keeps "
+                         "the whole node's pages resident and takes detector chunks from a per-node host-side queue (ocr_vi_invoice_amd.dist."
+                         "PageQueue: own shard first, then from the rank with most left) -- for unequal pages; no device collective either way")
+    ap.add_argument("--lines-skew", type=float, default=0.0,
+                    help="with N > 1 ranks: text lines per page vary linearly over the ranks' shards from lines*(1-skew) to lines*(1+skew) "
+                         "(an artificial imbalance for --balance queue to level)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cer-crops", type=int, default=256,
                     help="crops of the last step whose strings are compared with the CPU oracle's (cer_vs_cpu_ref, strings_differ_vs_cpu)")
@@ -165,6 +172,8 @@ class E2E:
         # the cgroup quota), at most 16 -- eight ranks on one host must not each take sixteen
         self.post_threads = args.post_threads or max(2, min(16, usable_cores(1 << 20) // max(1, n_ranks_on_host)))
         self.detected = args.boxes == "detected" and args.workload == "e2e"
+        self.queue = None               # dist.PageQueue in --balance queue mode (set by run_mode)
+        self.last_chunks = None
 
     # ---- inputs
     def load_inputs(self, images_u8, gt_boxes):
@@ -348,11 +357,12 @@ class E2E:
                 assert not self.open_steps and not self.inflight
                 self.results.put("flushed")
                 continue
-            step = job
+            step, chunk_q = job if isinstance(job, tuple) else (job, None)
             all_rects, counts = [], []
             self.open_steps[step] = rec = {"rects": None, "texts": [], "counts": counts, "nrows": 1 << 62}
             if self.detected:
-                for c in range(self.nchunk):
+                # static: the step's chunks are all of this rank's; queue mode: whatever the main thread took from the node's queue, as it takes them
+                for c in (range(self.nchunk) if chunk_q is None else iter(chunk_q.get, None)):
                     self.ev_map[step & 1][c].synchronize()
                     if self.dcomp is not None:   # (no fallback map is handed over: an overflowing page raises instead of being guessed)
                         rects, cnt, _ = self.dcomp[c].boxes(self.pp, None, 1.0, 1.0, (a.height, a.width), page_base=c * a.det_chunk,
@@ -383,6 +393,31 @@ class E2E:
         torch, a = self.torch, self.args
         self.room.acquire()
         k = self.nstep & 1
+        if self.queue is not None:       # --balance queue: chunks come from the node's page queue (detected-boxes e2e workload only)
+            from ocr_vi_invoice_amd.dist import drain_queue
+            chunk_q = queue.Queue()
+            self.jobs.put((self.nstep, chunk_q))     # the worker post-processes chunk by chunk while later ones are still being taken
+
+            def launch(c):
+                with torch.cuda.stream(self.s_det):
+                    if self.g_det is not None:
+                        self.g_det[c].replay()
+                    else:
+                        self._det_chunk(c)
+                    if self.dcomp is not None:
+                        self.d2h_bytes += self.dcomp[c].copy_async(slot=k)
+                    else:
+                        self.h_prob[k][c].copy_(self.prob[c], non_blocking=True)
+                    self.ev_map[k][c].record(self.s_det)
+                chunk_q.put(c)
+                return c
+
+            q = self.queue.for_step(self.nstep)
+            self.last_chunks = drain_queue(q, launch, lambda c: self.ev_map[k][c].synchronize(), depth=2)
+            self.stolen = getattr(self, "stolen", 0) + q.taken_stolen
+            chunk_q.put(None)
+            self.nstep += 1
+            return
         if self.det is not None:
             with torch.cuda.stream(self.s_det):
                 for c in range(self.nchunk):
@@ -430,7 +465,7 @@ class E2E:
         import numpy as np
         torch, a = self.torch, self.args
         if self.det is not None:
-            for c in range(self.nchunk):
+            for c in (range(self.nchunk) if self.last_chunks is None else self.last_chunks):
                 self._det_chunk(c)
         if self.rec is not None and rects is not None:
             rb = a.rec_batch
@@ -504,7 +539,27 @@ def run_mode(args, dtype, dev, cdev, det_blob, rec_blob, images_u8, boxes, local
     from ocr_vi_invoice_amd import _lib
     a = copy.copy(args)
     a.dtype = dtype
+    queue_mode = args.balance == "queue"
+    if queue_mode:
+        a.batch = images_u8.shape[0]         # every rank holds the node's pages; the queue decides who runs which chunk
     pipe = E2E(a, dev, det_blob, rec_blob, local_world)
+    if queue_mode:
+        from ocr_vi_invoice_amd.dist import PageQueue, default_store
+        if not pipe.detected:
+            raise SystemExit("bench.py: --balance queue needs the e2e workload with --boxes detected")
+        world = dist.get_world_size() if dist else 1
+        rank = dist.get_rank() if dist else 0
+
+        class _LocalStore:               # one rank: the queue only needs an atomic add
+            def __init__(self):
+                self.d = {}
+
+            def add(self, k, n):
+                self.d[k] = self.d.get(k, 0) + n
+                return self.d[k]
+
+        nchunk_node = (a.batch + a.det_chunk - 1) // a.det_chunk
+        pipe.queue = PageQueue(default_store(dist) if dist else _LocalStore(), f"bench-{dtype}", nchunk_node, rank, world)
     pipe.load_inputs(images_u8, boxes)
     pipe.capture()
     for _ in range(a.warmup):
@@ -542,6 +597,15 @@ def run_mode(args, dtype, dev, cdev, det_blob, rec_blob, images_u8, boxes, local
         prof = _lib.prof_report()
     out = {"dt": dt, "rank_dt": rank_dt, "rects": last_rects, "texts": texts, "counts": counts, "prof": prof, "detected": pipe.detected,
            "post_threads": pipe.post_threads, "images": pipe.images}
+    if queue_mode:
+        mine = float(sum(len(r[2]) for r in done))           # pages this rank processed over the timed steps
+        stolen = float(getattr(pipe, "stolen", 0))
+        if dist:
+            from ocr_vi_invoice_amd.dist import gather_over_ranks
+            out["pages_by_rank"] = gather_over_ranks(mine, cdev, dist)
+            out["chunks_stolen_by_rank"] = gather_over_ranks(stolen, cdev, dist)
+        else:
+            out["pages_by_rank"], out["chunks_stolen_by_rank"] = [mine], [stolen]
     if pipe.detected:   # bytes the post-processing stage pulls over PCIe per page (whole map, or mask + component table + box values)
         out["d2h_bytes_per_page"] = (int(pipe.d2h_bytes / ((a.steps + a.warmup) * a.batch)) if getattr(pipe, "dcomp", None) is not None
                                      else a.height * a.width * 4)
@@ -647,10 +711,15 @@ def main():
 
     # ---- synthetic inputs (this rank's shard)
     imgs, boxes = [], []
-    for i in range(args.batch):
-        im, bx = synth.make_invoice(1000 * rank + i, args.height, args.width, args.lines)
-        imgs.append(im)
-        boxes.append(np.concatenate([np.full((len(bx), 1), i, np.int32), bx], 1))
+    owners = range(world) if args.balance == "queue" else [rank]      # queue mode: every rank holds the node's pages (64 x 3.7 MB per rank)
+    for r in owners:
+        lines_r = args.lines
+        if world > 1 and args.lines_skew:
+            lines_r = max(1, int(round(args.lines * (1.0 + args.lines_skew * (2.0 * r / (world - 1) - 1.0)))))
+        for i in range(args.batch):
+            im, bx = synth.make_invoice(1000 * r + i, args.height, args.width, lines_r)
+            imgs.append(im)
+            boxes.append(np.concatenate([np.full((len(bx), 1), len(imgs) - 1, np.int32), bx], 1))
     images_u8 = np.stack(imgs)
     boxes = np.ascontiguousarray(np.concatenate(boxes, 0), dtype=np.int32)
     lib = _lib.load()
@@ -691,9 +760,13 @@ def main():
                                   ", det stream || host post-processing || rec stream; recogniser batches filled across steps, one padded batch at the flush"),
                        "post_process": {"in_timed_region": bool(m1["detected"]), "host_threads": m1["post_threads"], "mode": args.post,
                                         "d2h_bytes_per_page": m1.get("d2h_bytes_per_page")},
-                       "parallelism": f"replicas x{world}, images sharded, no collective"},
+                       "parallelism": f"replicas x{world}, images sharded, no collective" +
+                                      (", per-node page queue (whole pages, host side)" if args.balance == "queue" else "")},
             "ms_per_step_by_rank": rank_spread(m1),
         }
+        if args.balance == "queue":
+            res["page_queue"] = {"pages_by_rank": m1.get("pages_by_rank"), "chunks_stolen_by_rank": m1.get("chunks_stolen_by_rank"),
+                                 "lines_skew": args.lines_skew}
         if bcast_ms is not None:
             res["weight_broadcast_ms"] = round(bcast_ms, 2)
             res["weight_broadcast_bytes"] = len(det_blob) + len(rec_blob)

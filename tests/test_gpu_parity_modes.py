@@ -171,3 +171,27 @@ def test_bench_launcher_runs_two_ranks_from_a_plain_invocation():
     assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 8 and res["value"] > 0
     assert res["weight_broadcast_ms"] >= 0 and res["weight_broadcast_bytes"] > 50e6
     assert res["config"]["post_process"]["in_timed_region"] is True
+
+
+def test_bench_page_queue_two_ranks_process_every_page_once():
+    """`bench.py --balance queue` (SURVEY.md 8e work stealing of whole pages; pipeline2.py:279 is the serial loop): two ranks on this box's
+    one GPU (gloo rehearsal), rank 1's pages carrying more lines than rank 0's.  Every page of the node is processed exactly once per
+    step whoever takes it, and the strings are unaffected by who ran which chunk (same pages, same strings as the static run)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OCRVI_BENCH_REHEARSE="1")
+    env.pop("WORLD_SIZE", None)
+    base = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8", "--det-chunk", "2",
+            "--lines", "6", "--lines-skew", "0.5", "--height", "320", "--width", "480", "--rec-batch", "16", "--no-cpu-baseline", "--no-prof",
+            "--also", "none", "--dtype", "f16"]
+    out = {}
+    for mode in ("static", "queue"):
+        r = subprocess.run(base + ["--balance", mode], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[mode] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    q = out["queue"]
+    assert q["n_gpus"] == 2 and q["config"]["global_batch"] == 16 and q["value"] > 0
+    assert sum(q["page_queue"]["pages_by_rank"]) == 2 * 16                 # 2 timed steps x 16 pages: none dropped, none twice
+    assert "page queue" in q["config"]["parallelism"] and "page_queue" not in out["static"]
