@@ -69,18 +69,27 @@ __global__ __launch_bounds__(NWV * 64, (IsSplit<T>::value && MAXT <= 16 && NWV =
             vv = *(const uint4*)(base + (size_t)key * ld + 2 * D + ch * EPC);
         }
         const int sw = sizeof(T) == 4 ? swz128(key) : swz64(key);
-        *(uint4*)(Ks + key * KROW + ((ch ^ sw) << 4)) = kv;
         if constexpr (IsSplit<T>::value) {
-            // V^T rows keep the operand format ALONG THE KEYS: keys 4c .. 4c+3 of head-dim row d are the chunk [4 hi | 4 lo] at 16 c
+            // f16x2: both operands are staged in the form the three-product MFMAs consume -- per lane 32 bytes = [hi of its 8 k-slots | lo of
+            // them] -- so that a fragment is two ds_read_b128 and NO register regrouping (the K and V fragments of a query tile cost 6 v_mov
+            // each in the chunk format: 480 of the ~1000 VALU instructions per 16 queries at 240 keys, in a kernel that is VALU-bound).
+            // K row `key`: chunk 2 j holds the hi halves of channels 8 j .. 8 j + 7, chunk 2 j + 1 their lo halves: the hi (lo) half of memory
+            // chunk ch goes to bytes 8 (ch & 1) of LDS chunk (ch & ~1) (+ 1).
+            char* kr = Ks + key * KROW + (ch & 1) * 8;
+            *(uint2*)(kr + (((ch & ~1) ^ sw) << 4)) = make_uint2(kv.x, kv.y);
+            *(uint2*)(kr + (((ch | 1) ^ sw) << 4)) = make_uint2(kv.z, kv.w);
+            // V^T row d: 128 bytes per 32-key step s, lane group g at 32 g: [hi of keys 32 s + 4 g .. + 3 and 32 s + 16 + 4 g .. + 3 | lo of them]
             union { uint4 u; f16_t h[8]; } r;
             r.u = vv;
+            const int vo = (key >> 5) * 128 + ((key >> 2) & 3) * 32 + (((key >> 4) & 1) * 4 + (key & 3)) * 2;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                char* dst = Vt + (ch * 4 + e) * VS + (key >> 2) * 16 + (key & 3) * 2;
+                char* dst = Vt + (ch * 4 + e) * VS + vo;
                 *(f16_t*)dst = r.h[e];
-                *(f16_t*)(dst + 8) = r.h[4 + e];
+                *(f16_t*)(dst + 16) = r.h[4 + e];
             }
         } else {
+            *(uint4*)(Ks + key * KROW + ((ch ^ sw) << 4)) = kv;
             union { uint4 u; T e[EPC]; } r;
             r.u = vv;
 #pragma unroll
@@ -118,8 +127,8 @@ __global__ __launch_bounds__(NWV * 64, (IsSplit<T>::value && MAXT <= 16 && NWV =
                 for (int t = 0; t < MAXT; ++t) {
                     acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
                     const char* kr = Ksq + (t * 16 + lr) * KROW;
-                    U kH, kL;
-                    Mma<T>::regroup(*(const uint4*)(kr + o0), *(const uint4*)(kr + o1), kH, kL);
+                    const uint4 k0 = *(const uint4*)(kr + o0), k1 = *(const uint4*)(kr + o1);     // staged as (hi, lo) quartets
+                    const U kH = {k0.x, k0.y, k0.z, k0.w}, kL = {k1.x, k1.y, k1.z, k1.w};
                     Mma<T>::three(kH, kL, qH, qL, acc[t]);
                 }
             } else {
@@ -191,9 +200,9 @@ __global__ __launch_bounds__(NWV * 64, (IsSplit<T>::value && MAXT <= 16 && NWV =
                 Mma<T>::regroup(c0, c1, pH, pL);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
-                    const char* vr = Vtq + (dt * 16 + lr) * VS + (32 * s + 4 * g) * 4;   // the same keys of head-dim row 16 dt + lr (staged to whole 32-key steps)
-                    U vH, vL;
-                    Mma<T>::regroup(*(const uint4*)vr, *(const uint4*)(vr + 64), vH, vL);
+                    const char* vr = Vtq + (dt * 16 + lr) * VS + 128 * s + 32 * g;   // the same keys of head-dim row 16 dt + lr, staged as (hi, lo) quartets
+                    const uint4 v0 = *(const uint4*)vr, v1 = *(const uint4*)(vr + 16);
+                    const U vH = {v0.x, v0.y, v0.z, v0.w}, vL = {v1.x, v1.y, v1.z, v1.w};
                     Mma<T>::three(vH, vL, pH, pL, o[dt]);
                 }
             }
