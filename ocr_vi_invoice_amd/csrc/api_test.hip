@@ -223,7 +223,9 @@ extern "C" int ocrvi_test_attention(int device, int dtype, const float* qkv, int
     OCRVI_TRY(sc.alloc(nin * dtype_size(dtype), &q));
     OCRVI_TRY(sc.alloc(nout * dtype_size(dtype), &o));
     OCRVI_TRY(k_cast_from_f32(dtype, qkv, q, nin, sc.s));
-    OCRVI_TRY(timed(sc, iters, avg_ms, [&]() { return k_attention(dtype, q, o, B, N, heads, sc.s); }));
+    void* asc = nullptr;
+    if (const size_t sb = attention_scratch_bytes(dtype, B, N, heads)) OCRVI_TRY(sc.alloc(sb, &asc));
+    OCRVI_TRY(timed(sc, iters, avg_ms, [&]() { return k_attention(dtype, q, o, B, N, heads, sc.s, asc); }));
     // [B*N][D] T -> float32 (same layout): a C=1 "NHWC -> NCHW" copy is a plain cast
     OCRVI_TRY(k_nhwc_to_nchw_f32(dtype, o, out, 1, 1, (int)nout, 1, 1, 0, sc.s));
     OCRVI_HIP(hipStreamSynchronize(sc.s));

@@ -44,7 +44,11 @@ template <> __device__ __forceinline__ f32x4 mfma16<f16_t>(const uint4& a, const
 // (f16x2 up to 256 keys: 8 waves per workgroup at no more than 128 registers, so that the two workgroups a CU's LDS holds give every SIMD four waves:
 // a wave's QK -> softmax -> PV chain is latency-bound and needs neighbours)
 template <typename T, int MAXT, bool MASK, int NWV = 4>
-__global__ __launch_bounds__(NWV * 64, (IsSplit<T>::value && MAXT <= 16 && NWV == 8) ? 4 : 1) void attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int N, int heads) {
+__global__ __launch_bounds__(NWV * 64, (IsSplit<T>::value && MAXT <= 16 && NWV == 8) ? 4 : 1) void attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int N, int heads, int kbase, int Nk,
+                                                                                                               float* __restrict__ po, float2* __restrict__ pml) {
+    // (kbase, Nk): the key range [kbase, kbase + Nk) this launch attends to -- (0, N) normally.  Sequences beyond one workgroup's LDS
+    // (4-byte types: > 512 keys) run as several launches over key chunks in PARTIAL mode (po != null): the un-normalised output rows go to
+    // po [B][N][D] fp32 and (row max, row sum) to pml [B][heads][N]; attention_combine_kernel merges the chunks (flash-attention's split-K).
     constexpr int EPC = TypeInfo<T>::EPC;
     constexpr int KROW = AttnCfg<T>::KROW;
     constexpr int CH = KROW / 16;  // 16-byte chunks per K row
@@ -64,9 +68,9 @@ __global__ __launch_bounds__(NWV * 64, (IsSplit<T>::value && MAXT <= 16 && NWV =
     for (int idx = tid; idx < NP * CH; idx += NWV * 64) {
         const int key = idx / CH, ch = idx % CH;
         uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-        if (key < N) {
-            kv = *(const uint4*)(base + (size_t)key * ld + D + ch * EPC);
-            vv = *(const uint4*)(base + (size_t)key * ld + 2 * D + ch * EPC);
+        if (key < Nk) {
+            kv = *(const uint4*)(base + (size_t)(kbase + key) * ld + D + ch * EPC);
+            vv = *(const uint4*)(base + (size_t)(kbase + key) * ld + 2 * D + ch * EPC);
         }
         const int sw = sizeof(T) == 4 ? swz128(key) : swz64(key);
         if constexpr (IsSplit<T>::value) {
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(NWV * 64, (IsSplit<T>::value && MAXT <= 16 && NWV =
         // ---- softmax over keys (this lane: keys 16t + 4g + r of query lr)
         float mx = -INFINITY;
         if constexpr (MASK) {
-            int nlim = N - 4 * g;
+            int nlim = Nk - 4 * g;
             asm volatile("" : "+v"(nlim));  // opaque per q-tile: stops LICM from hoisting 4*MAXT compare masks into (spilled) SGPRs
 #pragma unroll
             for (int t = 0; t < MAXT; ++t)
@@ -246,6 +250,15 @@ __global__ __launch_bounds__(NWV * 64, (IsSplit<T>::value && MAXT <= 16 && NWV =
             sum += __shfl_xor(sum, 32);
         } else {
             sum = osum[0];
+        }
+        if (po) {      // partial mode (4-byte types): un-normalised rows + (max, sum) of this key chunk
+            if (qok) {
+                float* prow = po + ((size_t)b * N + q) * D + h * 32 + 4 * g;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) *(float4*)(prow + dt * 16) = make_float4(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
+                if (g == 0) pml[((size_t)b * heads + h) * N + q] = make_float2(mx, sum);
+            }
+            continue;
         }
         const float inv = 1.f / sum;
         if (qok) {
@@ -445,7 +458,7 @@ static int attn16_dt(const void* qkv, void* out, int B, int N, int heads, hipStr
 }
 
 template <typename T, int MAXT, bool MASK>
-static int launch_attn_m(const void* qkv, void* out, int B, int N, int heads, hipStream_t s) {
+static int launch_attn_m(const void* qkv, void* out, int B, int N, int heads, hipStream_t s, int kbase, int Nk, float* po, float2* pml) {
     constexpr int NP = ((MAXT + 1) / 2) * 32;
     const int smem = NP * AttnCfg<T>::KROW + 32 * AttnCfg<T>::vstride(NP);
     if constexpr (sizeof(T) == 4 && MAXT >= 30) {
@@ -453,7 +466,7 @@ static int launch_attn_m(const void* qkv, void* out, int B, int N, int heads, hi
         if (w8) {
             auto kern8 = attention_kernel<T, MAXT, MASK, 8>;
             OCRVI_TRY(ensure_max_smem((const void*)kern8, smem));
-            hipLaunchKernelGGL(kern8, dim3(heads * B), dim3(512), smem, s, (const T*)qkv, (T*)out, N, heads);
+            hipLaunchKernelGGL(kern8, dim3(heads * B), dim3(512), smem, s, (const T*)qkv, (T*)out, N, heads, kbase, Nk, po, pml);
             OCRVI_HIP(hipGetLastError());
             return OCRVI_OK;
         }
@@ -463,39 +476,103 @@ static int launch_attn_m(const void* qkv, void* out, int B, int N, int heads, hi
         if (w8) {
             auto kern8 = attention_kernel<T, MAXT, MASK, 8>;
             OCRVI_TRY(ensure_max_smem((const void*)kern8, smem));
-            hipLaunchKernelGGL(kern8, dim3(heads * B), dim3(512), smem, s, (const T*)qkv, (T*)out, N, heads);
+            hipLaunchKernelGGL(kern8, dim3(heads * B), dim3(512), smem, s, (const T*)qkv, (T*)out, N, heads, kbase, Nk, po, pml);
             OCRVI_HIP(hipGetLastError());
             return OCRVI_OK;
         }
     }
     auto kern = attention_kernel<T, MAXT, MASK, 4>;
     OCRVI_TRY(ensure_max_smem((const void*)kern, smem));
-    hipLaunchKernelGGL(kern, dim3(heads * B), dim3(256), smem, s, (const T*)qkv, (T*)out, N, heads);
+    hipLaunchKernelGGL(kern, dim3(heads * B), dim3(256), smem, s, (const T*)qkv, (T*)out, N, heads, kbase, Nk, po, pml);
     OCRVI_HIP(hipGetLastError());
     return OCRVI_OK;
 }
 
 template <typename T, int MAXT>
-static int launch_attn(const void* qkv, void* out, int B, int N, int heads, hipStream_t s) {
-    if (N == MAXT * 16) return launch_attn_m<T, MAXT, false>(qkv, out, B, N, heads, s);
-    return launch_attn_m<T, MAXT, true>(qkv, out, B, N, heads, s);
+static int launch_attn(const void* qkv, void* out, int B, int N, int heads, hipStream_t s, int kbase, int Nk, float* po, float2* pml) {
+    if (Nk == MAXT * 16) return launch_attn_m<T, MAXT, false>(qkv, out, B, N, heads, s, kbase, Nk, po, pml);
+    return launch_attn_m<T, MAXT, true>(qkv, out, B, N, heads, s, kbase, Nk, po, pml);
 }
+
+// keys [kbase, kbase + Nk) of sequences of N tokens (Nk <= 512); po / pml non-null = partial mode
+template <typename T>
+static int attn_range(const void* qkv, void* out, int B, int N, int heads, hipStream_t s, int kbase, int Nk, float* po, float2* pml) {
+    const int NT = (Nk + 15) >> 4;
+    if (NT <= 4) return launch_attn<T, 4>(qkv, out, B, N, heads, s, kbase, Nk, po, pml);   // 32x256 input: FRM rows, W/4 = 64
+    if (NT <= 5) return launch_attn<T, 5>(qkv, out, B, N, heads, s, kbase, Nk, po, pml);   // FRM rows, W/4 = 80
+    if (NT <= 8) return launch_attn<T, 8>(qkv, out, B, N, heads, s, kbase, Nk, po, pml);   // 32x256 input: stage 2, 128 tokens
+    if (NT <= 15) return launch_attn<T, 15>(qkv, out, B, N, heads, s, kbase, Nk, po, pml); // stage 2, 240 tokens
+    if (NT <= 16) return launch_attn<T, 16>(qkv, out, B, N, heads, s, kbase, Nk, po, pml); // 32x256 input: stage 1, 256 tokens
+    if (NT <= 30) return launch_attn<T, 30>(qkv, out, B, N, heads, s, kbase, Nk, po, pml); // stage 1, 480 tokens
+    return launch_attn<T, 32>(qkv, out, B, N, heads, s, kbase, Nk, po, pml);
+}
+
+// Merge of the key chunks of one long sequence: out = sum_c w_c o_c / sum_c w_c l_c with w_c = exp2((m_c - max_c m_c) scale log2e) -- the
+// chunks' un-normalised rows all carry exp(-their own max) (and, in f16x2, the same 2^12), which w_c brings onto the common maximum.
+template <typename T>
+__global__ void attention_combine_kernel(const float* __restrict__ po, const float2* __restrict__ pml, T* __restrict__ out, int B, int N, int heads, int nchunk) {
+    const int D = heads * 32;
+    const size_t total = (size_t)B * N * heads * 8;          // one thread per (row, head, 4 channels)
+    const size_t rowsD = (size_t)B * N * D, rowsH = (size_t)B * heads * N;
+    const float c2 = 0.17677669529663687f * 1.4426950408889634f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i & 7);
+        const size_t t = i >> 3;
+        const int h = (int)(t % heads);
+        const size_t bq = t / heads;                          // b * N + q
+        const size_t b = bq / N, q = bq % N;
+        float m = -INFINITY;
+        for (int c = 0; c < nchunk; ++c) m = fmaxf(m, pml[c * rowsH + (b * heads + h) * N + q].x);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f}, den = 0.f;
+        for (int c = 0; c < nchunk; ++c) {
+            const float2 ml = pml[c * rowsH + (b * heads + h) * N + q];
+            const float w = __builtin_amdgcn_exp2f((ml.x - m) * c2);
+            const float4 o = *(const float4*)(po + c * rowsD + bq * D + h * 32 + c4 * 4);
+            acc[0] += w * o.x; acc[1] += w * o.y; acc[2] += w * o.z; acc[3] += w * o.w;
+            den += w * ml.y;
+        }
+        const float inv = 1.f / den;
+        const float ov[4] = {acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv};
+        store4<T>(out + bq * D + h * 32 + c4 * 4, ov);
+    }
+}
+
+static inline int attn_chunks(int N) { return (N + 511) / 512; }
+static inline int attn_chunk_keys(int N) { return (int)align_up((size_t)cdiv(N, attn_chunks(N)), 32); }
 
 template <typename T>
-static int attn_dt(const void* qkv, void* out, int B, int N, int heads, hipStream_t s) {
-    const int NT = (N + 15) >> 4;
-    if (NT <= 4) return launch_attn<T, 4>(qkv, out, B, N, heads, s);   // 32x256 input: FRM rows, W/4 = 64
-    if (NT <= 5) return launch_attn<T, 5>(qkv, out, B, N, heads, s);   // FRM rows, W/4 = 80
-    if (NT <= 8) return launch_attn<T, 8>(qkv, out, B, N, heads, s);   // 32x256 input: stage 2, 128 tokens
-    if (NT <= 15) return launch_attn<T, 15>(qkv, out, B, N, heads, s); // stage 2, 240 tokens
-    if (NT <= 16) return launch_attn<T, 16>(qkv, out, B, N, heads, s); // 32x256 input: stage 1, 256 tokens
-    if (NT <= 30) return launch_attn<T, 30>(qkv, out, B, N, heads, s); // stage 1, 480 tokens
-    return launch_attn<T, 32>(qkv, out, B, N, heads, s);
+static int attn_dt(const void* qkv, void* out, int B, int N, int heads, hipStream_t s, void* scratch) {
+    if (N <= 512) return attn_range<T>(qkv, out, B, N, heads, s, 0, N, nullptr, nullptr);
+    if constexpr (sizeof(T) == 4) {
+        OCRVI_CHECK(scratch, OCRVI_EINVAL, "attention: %d keys need the chunk scratch (attention_scratch_bytes)", N);
+        const int nc = attn_chunks(N), ck = attn_chunk_keys(N);
+        const size_t rowsD = (size_t)B * N * heads * 32, rowsH = (size_t)B * heads * N;
+        float* po = (float*)scratch;
+        float2* pml = (float2*)(po + (size_t)nc * rowsD);
+        for (int c = 0; c < nc; ++c) {
+            const int k0 = c * ck, nk = std::min(ck, N - k0);
+            OCRVI_TRY(attn_range<T>(qkv, out, B, N, heads, s, k0, nk, po + (size_t)c * rowsD, pml + (size_t)c * rowsH));
+        }
+        const size_t total = rowsH * 8;
+        hipLaunchKernelGGL(attention_combine_kernel<T>, dim3((unsigned)std::min<size_t>((total + 255) / 256, 65535)), dim3(256), 0, s, po, pml, (T*)out, B, N, heads, nc);
+        OCRVI_HIP(hipGetLastError());
+        return OCRVI_OK;
+    } else {
+        set_error("attention: the register-resident 16-bit kernel takes at most 512 keys");
+        return OCRVI_EINVAL;
+    }
 }
 
-int k_attention(int dtype, const void* qkv, void* out, int B, int N, int heads, hipStream_t s) {
+size_t attention_scratch_bytes(int dtype, int B, int N, int heads) {
+    if (dtype_size(dtype) != 4 || N <= 512) return 0;
+    return (size_t)attn_chunks(N) * ((size_t)B * N * heads * 32 * 4 + (size_t)B * heads * N * 8);
+}
+
+int k_attention(int dtype, const void* qkv, void* out, int B, int N, int heads, hipStream_t s, void* scratch) {
     OCRVI_CHECK(qkv && out && B > 0 && B < 65536 && heads > 0 && N > 0, OCRVI_EINVAL, "attention: bad shape B=%d N=%d heads=%d", B, N, heads);
-    OCRVI_CHECK(N <= 512, OCRVI_EINVAL, "attention: sequence length %d > 512 unsupported (crop wider than ~340 px at height 48)", N);
+    // 16-bit types: the streaming kernel stages every key (128 B each) in one workgroup's LDS; 4-byte types: key chunks of <= 512 + a merge
+    OCRVI_CHECK(N <= (dtype_size(dtype) == 2 ? 1024 : 4096), OCRVI_EINVAL, "attention: sequence length %d unsupported (at most %d tokens in this mode)", N,
+                dtype_size(dtype) == 2 ? 1024 : 4096);
     char tag[64];
     snprintf(tag, sizeof(tag), "attention_hd32_%s", dtype_name(dtype));
     const double esz = (double)dtype_size(dtype);
@@ -505,10 +582,10 @@ int k_attention(int dtype, const void* qkv, void* out, int B, int N, int heads, 
     static const bool streaming = !(getenv("OCRVI_ATTN_STREAM") && atoi(getenv("OCRVI_ATTN_STREAM")) == 0);
     OCRVI_CHECK((size_t)B * heads < ((size_t)1 << 31), OCRVI_EINVAL, "attention: too many (sequence, head) pairs");
     switch (dtype) {
-        case OCRVI_F32: return attn_dt<float>(qkv, out, B, N, heads, s);
-        case OCRVI_BF16: return streaming && N > 256 ? attn16_dt<bf16_t>(qkv, out, B, N, heads, s) : attn_dt<bf16_t>(qkv, out, B, N, heads, s);
-        case OCRVI_F16: return streaming && N > 256 ? attn16_dt<f16_t>(qkv, out, B, N, heads, s) : attn_dt<f16_t>(qkv, out, B, N, heads, s);
-        case OCRVI_F16X2: return attn_dt<f16x2_t>(qkv, out, B, N, heads, s);
+        case OCRVI_F32: return attn_dt<float>(qkv, out, B, N, heads, s, scratch);
+        case OCRVI_BF16: return (streaming && N > 256) || N > 512 ? attn16_dt<bf16_t>(qkv, out, B, N, heads, s) : attn_dt<bf16_t>(qkv, out, B, N, heads, s, scratch);
+        case OCRVI_F16: return (streaming && N > 256) || N > 512 ? attn16_dt<f16_t>(qkv, out, B, N, heads, s) : attn_dt<f16_t>(qkv, out, B, N, heads, s, scratch);
+        case OCRVI_F16X2: return attn_dt<f16x2_t>(qkv, out, B, N, heads, s, scratch);
     }
     set_error("unknown dtype %d", dtype);
     return OCRVI_EINVAL;

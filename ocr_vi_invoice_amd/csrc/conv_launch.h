@@ -119,7 +119,9 @@ int launch_gemm_ring(const ConvParams& p_in, int amode, hipStream_t stream) {
     // (f16x2: 4-byte operands like fp32, but its 256-row build -- 255 VGPRs, no scratch -- fits, and the kernel is bound by the bytes it
     // streams per FLOP, not by the matrix pipe: 256 x 128 tiles move 2/3 of the bytes of 128 x 128 ones)
     const bool wide_ok = sizeof(T) == 2 || IsSplit<T>::value;
-    const int bm = bn == 64 ? 256 : ((wide_ok && ((nk >= 4 && big_m) || mid256)) ? 256 : 128);
+    // (f16x2 3x3 mode: 128-row tiles -- the 256-row build with the 3x3 mode's per-piece pointers and tap masks needs 8 VGPRs more than a wave has)
+    const bool c3_x2 = IsSplit<T>::value && amode == AM_CONV3;
+    const int bm = bn == 64 ? 256 : ((wide_ok && !c3_x2 && ((nk >= 4 && big_m) || mid256)) ? 256 : 128);
     // one persistent workgroup per CU; a workgroup keeps its column tile, so the grid is Gm row-tile lanes x ntiles, with Gm chosen
     // for equal row-tile counts
     const int mtiles = cdiv(p.M, bm);
@@ -136,6 +138,9 @@ int launch_gemm_ring(const ConvParams& p_in, int amode, hipStream_t stream) {
     }
     if constexpr (sizeof(T) == 2 || IsSplit<T>::value) {
         if (bm == 256) return launch_ring_cfg<T, 256, 8, 1>(p, amode, grid, stream);
+    }
+    if constexpr (IsSplit<T>::value) {
+        if (amode == AM_CONV3) return launch_ring_f<T, 128, 8, 2, true, true>(p, grid, stream);
     }
     return launch_ring_cfg<T, 128, 8, 2>(p, amode, grid, stream);  // MI = 2: one group
 }

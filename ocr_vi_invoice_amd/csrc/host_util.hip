@@ -226,7 +226,8 @@ bool gemm_ring_eligible(const ConvParams& p, int amode, int dtype) {
     if (!on || p.groups != 1 || p.store_mode != ST_NHWC) return false;
     const int esz = (int)dtype_size(dtype), bke = conv_bke(dtype);
     if (amode == AM_CONV3) {  // 3x3 / stride 1 / pad 1 on the ring: 16-bit types, whole channel blocks per tap, 256-row tiles
-        if (!on3 || esz != 2 || p.out_f32 || p.KH != 3 || p.SH != 1 || p.SW != 1 || p.PH != 1 || p.PW != 1 || p.H != p.OH || p.W != p.OW) return false;
+        static const bool x2c3 = getenv("OCRVI_RING_CONV3_X2") && atoi(getenv("OCRVI_RING_CONV3_X2"));   // experiment: f16x2 3x3 on the ring's 128-row build
+        if (!on3 || !(esz == 2 || (x2c3 && dtype == OCRVI_F16X2)) || (p.out_f32 && esz == 2) || p.KH != 3 || p.SH != 1 || p.SW != 1 || p.PH != 1 || p.PW != 1 || p.H != p.OH || p.W != p.OW) return false;
         // measured (profiles/r01_conv_variants.md): +5..9 % over conv_gemm at M >= 300 k rows, -12 % at 77 k (too few tiles per CU)
         static const int min_m = getenv("OCRVI_RING_CONV3_MIN_M") ? atoi(getenv("OCRVI_RING_CONV3_MIN_M")) : (1 << 18);
         if (p.Cin_g % bke != 0 || p.Kp != 9 * p.Cin_g || p.M < min_m || p.Np % 128 != 0) return false;  // (64-wide: conv_gemm is 6 % faster)

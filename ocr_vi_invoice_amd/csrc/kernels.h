@@ -25,8 +25,10 @@ int k_cast_from_f32(int dtype, const float* x, void* y, size_t n, hipStream_t s)
 int k_nhwc_to_nchw_f32(int dtype, const void* x, float* y, int N, int H, int W, int C, int ld, int coff, hipStream_t s);
 
 // Multi-head self-attention, head_dim 32 (svtrv2.py:77-86, 199-213): qkv T [B*N][3*heads*32] -> out T [B*N][heads*32].
-// N <= 512.
-int k_attention(int dtype, const void* qkv, void* out, int B, int N, int heads, hipStream_t s);
+// 16-bit types: N <= 1024.  4-byte types: N <= 512 in one pass; longer sequences run as key chunks of <= 512 merged by a second kernel and
+// need `scratch` = attention_scratch_bytes(..) bytes of device memory (0 for N <= 512).
+int k_attention(int dtype, const void* qkv, void* out, int B, int N, int heads, hipStream_t s, void* scratch = nullptr);
+size_t attention_scratch_bytes(int dtype, int B, int N, int heads);
 // FRM vertical cross-attention with the precomputed query (svtrv2.py:236-243): kv T [B*H*W][2D] (token = h*W + w per image),
 // vq f32 [D] -> out T [B*W][D].
 int k_frm_vertical(int dtype, const void* kv, const float* vq, void* out, int B, int H, int W, int D, hipStream_t s);

@@ -148,8 +148,12 @@ static int check_rec_shape(const ocrvi_rec* h, int B, int H, int W) {
     OCRVI_CHECK(h, OCRVI_EINVAL, "rec: null handle");
     OCRVI_CHECK(B > 0 && H > 0 && W > 0 && H % 16 == 0 && W % 4 == 0, OCRVI_EINVAL,
                 "rec: input (B=%d,3,%d,%d) needs H %% 16 == 0 and W %% 4 == 0", B, H, W);
-    OCRVI_CHECK((H / 4) * (W / 4) / 2 <= 512 && H / 16 <= 8, OCRVI_EINVAL,
-                "rec: %dx%d gives more than 512 tokens in the first global-attention stage (unsupported)", H, W);
+    // svtrv2.py:503-536 takes any size; here the first global-attention stage sees (H/8)(W/4) tokens: the 16-bit kernels stage every key
+    // in one workgroup's LDS (<= 1024), the 4-byte modes split the keys into chunks of <= 512 and merge (attention.hip), FRM's vertical
+    // attention takes up to 8 rows
+    const int tok = (H / 4) * (W / 4) / 2, tok_max = dtype_size(h->cfg.dtype) == 2 ? 1024 : 4096;
+    OCRVI_CHECK(tok <= tok_max && H / 16 <= 8, OCRVI_EINVAL,
+                "rec: %dx%d gives %d tokens in the first global-attention stage (at most %d in this mode) or more than 8 rows after the backbone", H, W, tok, tok_max);
     OCRVI_CHECK((size_t)B * (H / 2) * (W / 2) < ((size_t)1 << 23), OCRVI_EINVAL, "rec: batch of %d %dx%d crops too large for one call (chunk it)", B, H, W);
     return OCRVI_OK;
 }
@@ -250,7 +254,12 @@ static int rec_run(ocrvi_rec* h, Runner& r, const float* x, int B, int H, int W,
             } else {  // x + proj(MHSA(qkv(LN x)))  (svtrv2.py:77-86,98)
                 ConvOpts o;
                 OCRVI_TRY(conv(r, bw.qkv, view(xn, rows, 1, 1, d), view(big, rows, 1, 1, 3 * d), o));
-                if (!r.dry()) OCRVI_TRY(k_attention(dt, big.p, t1.p, B, Hs * Ws, d / 32, r.stream));
+                {   // (sequences beyond 512 keys in the 4-byte modes: per-chunk partial rows, merged; scratch from the arena)
+                    const size_t mk = r.arena.mark(), sb = attention_scratch_bytes(dt, B, Hs * Ws, d / 32);
+                    void* asc = sb ? r.arena.alloc(sb) : nullptr;
+                    if (!r.dry()) OCRVI_TRY(k_attention(dt, big.p, t1.p, B, Hs * Ws, d / 32, r.stream, asc));
+                    r.arena.release(mk);
+                }
                 o.res = &xs; o.res_mode = RES_SAME;
                 OCRVI_TRY(conv(r, bw.proj, view(t1, rows, 1, 1, d), view(xs, rows, 1, 1, d), o));
             }
@@ -287,7 +296,12 @@ static int rec_run(ocrvi_rec* h, Runner& r, const float* x, int B, int H, int W,
     {
         ConvOpts o;
         OCRVI_TRY(conv(r, h->h_qkv, xn, view(big, rows, 1, 1, 3 * d2), o));
-        if (!r.dry()) OCRVI_TRY(k_attention(dt, big.p, t1.p, B * Hs, Ws, d2 / 32, r.stream));  // one sequence per image row
+        {   // one sequence per image row
+            const size_t mk = r.arena.mark(), sb = attention_scratch_bytes(dt, B * Hs, Ws, d2 / 32);
+            void* asc = sb ? r.arena.alloc(sb) : nullptr;
+            if (!r.dry()) OCRVI_TRY(k_attention(dt, big.p, t1.p, B * Hs, Ws, d2 / 32, r.stream, asc));
+            r.arena.release(mk);
+        }
         o.res = &bn; o.res_mode = RES_SAME;
         OCRVI_TRY(conv(r, h->h_proj, t1, xr, o));
     }

@@ -300,7 +300,10 @@ def test_deform_conv_zero_offset_identity():
 @pytest.mark.parametrize("dt", ["f32", "f16x2", "bf16", "f16"])
 @pytest.mark.parametrize("B,N,heads", [(2, 480, 8), (3, 240, 12), (4, 80, 12), (2, 100, 2), (1, 512, 1), (2, 16, 3),
                                        # > 256 keys with N % 32 != 0: the streaming kernel's key masking (a 48x200 crop has 300 tokens)
-                                       (2, 300, 4), (1, 264, 2), (1, 500, 1)])
+                                       (2, 300, 4), (1, 264, 2), (1, 500, 1),
+                                       # > 512 keys (a 64x320 crop has 640 tokens in the first global stage): 16-bit types stream them from one
+                                       # workgroup's LDS, the 4-byte modes run key chunks of <= 512 in partial mode and merge them
+                                       (2, 640, 8), (1, 1000, 2), (1, 513, 1)])
 def test_attention_kernel(B, N, heads, dt):
     L = _lib()
     lib = L.load()
@@ -320,10 +323,10 @@ def test_attention_kernel(B, N, heads, dt):
 
 def test_attention_rejects_long_sequences():
     L = _lib()
-    qkv = torch.zeros(1, 600, 96, device="cuda")
-    out = torch.empty(1, 600, 32, device="cuda")
-    with pytest.raises(ValueError):
-        L.check(L.load().ocrvi_test_attention(0, 1, qkv.data_ptr(), 1, 600, 1, out.data_ptr(), 0, None))
+    qkv = torch.zeros(1, 1100, 96, device="cuda")
+    out = torch.empty(1, 1100, 32, device="cuda")
+    with pytest.raises(ValueError):      # 16-bit types: every key of a sequence is staged in one workgroup's LDS
+        L.check(L.load().ocrvi_test_attention(0, 1, qkv.data_ptr(), 1, 1100, 1, out.data_ptr(), 0, None))
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])

@@ -94,6 +94,35 @@ def test_svtrv2_batch_invariance_and_ragged_batch():
         np.testing.assert_allclose(single[:, 0].cpu().numpy(), full[:, i].cpu().numpy(), atol=1e-5)
 
 
+@pytest.mark.parametrize("dt", ["f32", "f16x2", "f16", "bf16"])
+def test_svtrv2_takes_crops_beyond_512_first_stage_tokens(dt):
+    """svtrv2.py:503-536 accepts any input size and pipeline2.py:219-220 exposes --rec_img_height / --rec_img_width: a 64x320 crop has
+    (64/8)(320/4) = 640 tokens in the first global-attention stage -- more than one workgroup's LDS holds in the 4-byte modes, which
+    run the keys in chunks and merge.  Against the CPU oracle at the same size; parity modes at the parity bar."""
+    from ocr_vi_invoice_amd import SVTRv2, synth, weights
+    from oracle import svtrv2_cpu
+    sd = weights.make_rec_state_dict("tiny", seed=21)
+    x = torch.from_numpy(synth.pad_crop_batch(synth.make_crops(8, 3, height=64, max_width=320), 64, 320))
+    ref = svtrv2_cpu.forward(sd, x, "tiny")
+    m = SVTRv2("tiny", state_dict=sd, dtype=dt)
+    lp = m(x.cuda())
+    assert lp.shape == ref.shape == (80, 3, 232)
+    err = float((lp.cpu() - ref).abs().max())
+    print(f"\n[{dt}] 64x320 crops (640 first-stage tokens): log_probs max-abs-err {err:.2e}")
+    if dt in PARITY:
+        assert err < 1e-3
+        assert m.decode_probs(lp) == m.tokenizer.decode(svtrv2_cpu.greedy_ids(ref))
+    else:
+        assert err < (0.25 if dt == "bf16" else 0.04)
+    if dt in PARITY:       # a 96x512 crop: 1536 tokens, three key chunks
+        x2 = torch.from_numpy(synth.pad_crop_batch(synth.make_crops(9, 1, height=96, max_width=512), 96, 512))
+        ref2 = svtrv2_cpu.forward(sd, x2, "tiny")
+        assert float((m(x2.cuda()).cpu() - ref2).abs().max()) < 1e-3
+    else:
+        with pytest.raises(ValueError, match="tokens"):
+            m(torch.zeros(1, 3, 96, 512, device="cuda"))           # 1536 tokens: beyond the 16-bit kernel's LDS
+
+
 def test_svtrv2_bad_shapes_raise():
     from ocr_vi_invoice_amd import SVTRv2
     m = SVTRv2("tiny", dtype="bf16")
