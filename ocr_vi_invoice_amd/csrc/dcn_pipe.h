@@ -156,7 +156,17 @@ __global__ __launch_bounds__(512, 2) void dcn_pipe_kernel(const ConvParams p) {
                     }
                 }
                 const int row = grow + 64 * it;
-                *(uint4*)(slab + row * 128 + ((gj ^ swz128(row)) << 4)) = Chunk<T>::pack(acc);
+                if constexpr (IsSplit<T>::value) {
+                    // the slab holds (hi, lo) QUARTETS: chunk 2 j = the hi halves of channels 8 j .. 8 j + 7, chunk 2 j + 1 their lo halves (the
+                    // weights are packed the same way, pack_conv), so the MFMA stage reads its operands without regrouping them: 12 + 6 NI
+                    // v_mov less per wave and step in a kernel that is VALU-bound
+                    const uint4 e = Chunk<T>::pack(acc);
+                    char* d = slab + row * 128 + (gj & 1) * 8;
+                    *(uint2*)(d + (((gj & ~1) ^ swz128(row)) << 4)) = make_uint2(e.x, e.y);
+                    *(uint2*)(d + (((gj | 1) ^ swz128(row)) << 4)) = make_uint2(e.z, e.w);
+                } else {
+                    *(uint4*)(slab + row * 128 + ((gj ^ swz128(row)) << 4)) = Chunk<T>::pack(acc);
+                }
             }
         };
         f32x4 acc[NI][2];
@@ -167,14 +177,12 @@ __global__ __launch_bounds__(512, 2) void dcn_pipe_kernel(const ConvParams p) {
             const char* Bs = Wr + (ks % 3) * WST + (wn * (BN / 2) + brow) * 128;
             if constexpr (IsSplit<T>::value) {   // f16x2: three MFMAs per fragment pair (Mma<f16x2_t>::regroup / three)
                 typedef typename Mma<T>::u4v U;
-                U xH[2], xL[2];
-                Mma<T>::regroup(*(const uint4*)(As + foa0), *(const uint4*)(As + foa1), xH[0], xL[0]);
-                Mma<T>::regroup(*(const uint4*)(As + 16 * 128 + foa0), *(const uint4*)(As + 16 * 128 + foa1), xH[1], xL[1]);
+                auto q16 = [](const char* q) -> U { const uint4 v = *(const uint4*)q; return (U){v.x, v.y, v.z, v.w}; };
+                const U xH[2] = {q16(As + foa0), q16(As + 16 * 128 + foa0)}, xL[2] = {q16(As + foa1), q16(As + 16 * 128 + foa1)};   // quartets (blend / pack_conv)
 #pragma unroll
                 for (int a = 0; a < NI; ++a) {
                     const char* r = Bs + (16 * a) * 128;      // (PERM is false for a 4-byte type)
-                    U wH, wL;
-                    Mma<T>::regroup(*(const uint4*)(r + fob0), *(const uint4*)(r + fob1), wH, wL);
+                    const U wH = q16(r + fob0), wL = q16(r + fob1);
                     Mma<T>::three(wH, wL, xH[0], xL[0], acc[a][0]);
                     Mma<T>::three(wH, wL, xH[1], xL[1], acc[a][1]);
                 }

@@ -109,7 +109,7 @@ void convert_to_dtype(const float* src, size_t n, int dtype, void* dst, float sc
 }
 
 // ------------------------------------------------------------------ weight packing
-static PackedConv finish_pack(const std::vector<float>& wt, int groups, int Np, int Kp, int dtype) {
+static PackedConv finish_pack(const std::vector<float>& wt, int groups, int Np, int Kp, int dtype, bool quartets = false) {
     PackedConv pc;
     pc.bytes.resize(wt.size() * dtype_size(dtype));
     float scale = 1.f;
@@ -127,6 +127,12 @@ static PackedConv finish_pack(const std::vector<float>& wt, int groups, int Np, 
         pc.wscale = 1.0f / scale;
     }
     convert_to_dtype(wt.data(), wt.size(), dtype, pc.bytes.data(), scale);
+    if (quartets && dtype == OCRVI_F16X2) {
+        // (hi, lo) quartet form for kernels that read a lane's 8 k-slots as two 16-byte operands without regrouping them in registers
+        // (dcn_pipe.h): every 32-byte group of 8 consecutive k-slots [hi4 lo4 | hi4' lo4'] becomes [hi4 hi4' | lo4 lo4']
+        uint64_t* q = (uint64_t*)pc.bytes.data();
+        for (size_t i = 0; i + 3 < pc.bytes.size() / 8; i += 4) std::swap(q[i + 1], q[i + 2]);
+    }
     pc.Np = Np;
     pc.Kp = Kp;
     pc.groups = groups;
@@ -158,7 +164,7 @@ PackedConv pack_conv(const float* w, const float* bias, int cout, int cin_g, int
                         else dst[(r * kw + s) * cin_g + c] = v;                      // [tap][cin]
                     }
         }
-    PackedConv pc = finish_pack(wt, groups, Np, Kp, dtype);
+    PackedConv pc = finish_pack(wt, groups, Np, Kp, dtype, amode == AM_DCN && dcn_pipe_packing(dtype, cin_g));
     pc.N_g = n_g;
     pc.Cin_g = cin_g;
     pc.KH = kh;

@@ -267,18 +267,15 @@ def test_dbnet_bad_shapes_raise():
 @pytest.mark.parametrize("dt", PARITY)
 @pytest.mark.parametrize("shape", [(1, 16, 8), (3, 32, 100), (2, 48, 36), (1, 64, 320), (5, 16, 512)])
 def test_svtrv2_small_and_ragged_shapes_match_oracle(shape, dt):
-    """Edge shapes: minimum height 16 (one token row after both merges), widths that give odd / tiny token counts (T = 2, 25, 9),
-    the widest sequence the attention kernel holds (64x320 -> 640 / 320 tokens... first global stage 8*80 = 640 > 512 is rejected)."""
+    """Edge shapes: minimum height 16 (one token row after both merges), widths that give odd / tiny token counts (T = 2, 25, 9), and
+    a 64x320 crop whose first global stage has 8 * 80 = 640 tokens (more than one attention workgroup's LDS holds in the 4-byte modes:
+    key chunks + merge, csrc/attention.hip)."""
     from ocr_vi_invoice_amd import SVTRv2, weights
     from oracle import svtrv2_cpu
     B, H, W = shape
     sd = weights.make_rec_state_dict("tiny", seed=5)
     m = SVTRv2("tiny", state_dict=sd, dtype=dt)
     x = torch.randn(B, 3, H, W, generator=torch.Generator().manual_seed(H * W))
-    if (H // 8) * (W // 4) > 512:
-        with pytest.raises(ValueError, match="512 tokens"):
-            m(x.cuda())
-        return
     ref = svtrv2_cpu.forward(sd, x, "tiny")
     lp = m(x.cuda())
     assert lp.shape == (W // 4, B, 232)
