@@ -3,7 +3,7 @@
 # Run on the GPU box from the repo root:  bash tools/profile_round.sh r02
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
