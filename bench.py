@@ -478,7 +478,7 @@ class E2E:
         torch.cuda.synchronize()
 
 
-def cpu_baseline(args, det_sd, rec_sd, image_u8, crops_f32, gpu_texts):
+def cpu_baseline(args, det_sd, rec_sd, image_u8, crops_f32, gpu_texts, prob_page=None):
     """Oracle (CPU restatement, `kind: port`) timed on this host as SURVEY.md 8d prescribes: ONE full page through the detector and
     32-crop batches through the recogniser (the reference's batching: 1 image per det forward pipeline2.py:279-317, 32 crops per rec
     forward :221), one warm-up then the median of 3, torch.set_num_threads(cores available).  Also the CER of the GPU strings against
@@ -490,7 +490,7 @@ def cpu_baseline(args, det_sd, rec_sd, image_u8, crops_f32, gpu_texts):
     from oracle import dbnet_cpu, svtrv2_cpu
     avail = usable_cores(16)
     torch.set_num_threads(avail)
-    t_det = t_rec = 0.0
+    t_det = t_rec = t_post = t_pre = 0.0
     sample = []
     if args.workload != "rec":
         x = torch.from_numpy(synth.normalize_chw(image_u8))[None]
@@ -501,6 +501,23 @@ def cpu_baseline(args, det_sd, rec_sd, image_u8, crops_f32, gpu_texts):
             ts.append(time.perf_counter() - t0)
         t_det = float(np.median(ts[1:]))
         sample.append(f"detector: one full {args.height}x{args.width} page, 1 warm-up + median of 3")
+    if args.workload == "e2e" and prob_page is not None:
+        # the host stages between the two models, as the reference runs them per image (pipeline2.py:320-343, src/det/test.py:20-130;
+        # pipeline2.py:92-128): DB post-processing of the page's (blended) probability map and crop + resize + normalise of its boxes, by
+        # the oracle's restatements of cv2 / pyclipper (single-threaded Python + numpy, like the reference's own loop)
+        from oracle import dbpost_cpu, preproc_cpu
+        ts, tp = [], []
+        for i in range(3):
+            t0 = time.perf_counter()
+            polys, _ = dbpost_cpu.db_postprocess(prob_page, 0.3, 0.5, 1000, 1.6)
+            rects = [dbpost_cpu.rescale_and_rect(q, 1.0, 1.0, args.height, args.width)[1] for q in polys]
+            t1 = time.perf_counter()
+            for r in rects:
+                preproc_cpu.preprocess_for_recognition(preproc_cpu.crop_image(image_u8, r), (48, 320))
+            ts.append(t1 - t0)
+            tp.append(time.perf_counter() - t1)
+        t_post, t_pre = float(np.median(ts)), float(np.median(tp))
+        sample.append(f"DB post-processing + crop pre-processing of that page ({len(rects)} boxes): oracle restatements of cv2 / pyclipper, median of 3")
     cer_cpu = None
     if args.workload != "det":
         n = min(32, crops_f32.shape[0])
@@ -522,14 +539,13 @@ def cpu_baseline(args, det_sd, rec_sd, image_u8, crops_f32, gpu_texts):
         n_cer = len(ref_txt)
         cer_cpu = {"cer": cer(gpu_texts[:n_cer], ref_txt), "crops": n_cer,
                    "strings_differ": sum(a != b for a, b in zip(gpu_texts[:n_cer], ref_txt))}
-    total = t_det + t_rec
+    total = t_det + t_post + t_pre + t_rec
     if args.workload == "rec":
         val, unit = args.lines / total, "crops/s"
     else:
         val, unit = 1.0 / total, "images/s"
-    note = "DB post-processing and crop pre-processing are not in the CPU figure (the reference uses cv2/pyclipper there; absent here)"
-    return {"value": round(val, 4), "unit": unit, "cores": avail, "kind": "port", "sample": "; ".join(sample) + "; " + note,
-            "det_s": round(t_det, 3), "rec_s": round(t_rec, 3)}, cer_cpu
+    return {"value": round(val, 4), "unit": unit, "cores": avail, "kind": "port", "sample": "; ".join(sample),
+            "det_s": round(t_det, 3), "post_s": round(t_post, 4), "crop_prep_s": round(t_pre, 4), "rec_s": round(t_rec, 3)}, cer_cpu
 
 
 def run_mode(args, dtype, dev, cdev, det_blob, rec_blob, images_u8, boxes, local_world, dist, lib):
@@ -621,10 +637,16 @@ def run_mode(args, dtype, dev, cdev, det_blob, rec_blob, images_u8, boxes, local
 
 
 def roofline_of(prof, dtype):
+    import re
+
     def roof(name, d):
         secs = d["ms"] / 1e3
         if d["flops"] > 0:
             ach, peak, u, bound = d["flops"] / secs / 1e12, PEAK_TFLOPS[dtype], "TFLOP/s", "mfma"
+            # conv_gemm's 64- and 32-column f16x2 tiles keep the four-product chunk form (a.b + swap(a).b): their matrix-pipe roof is a quarter
+            # of the 16-bit peak, not a third (the direct offset conv, 128 x 32, runs three products)
+            if dtype == "f16x2" and re.search(r"_128x(64|32)_f16x2$", name) and not name.startswith("dcn_offset"):
+                peak = 2500.0 / 4
         else:
             ach, peak, u, bound = d["bytes"] / secs / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
         return {"kernel": name, "bound": bound, "achieved": round(ach, 2), "peak": round(peak, 1), "unit": u, "frac": round(ach / peak, 4)}
@@ -805,7 +827,15 @@ def main():
                     tm["strings_differ_vs_headline"] = [sum(x != y for x, y in zip(m2["texts"], texts)), len(texts)]
             res["exact_fp32_mode" if mode == "f32" else ("throughput_mode" if mode not in PARITY_MODES else mode + "_mode")] = tm
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only
-            cb, cer_cpu = cpu_baseline(args, det_sd, rec_sd, images_u8[0], crops_all, texts)
+            prob0 = None
+            if m1["detected"]:   # page 0's map as the post-processor saw it: the synthetic text kernels over a structureless detector map
+                prob0 = np.zeros((args.height, args.width), np.float32)
+                for pg, x, y, w, h in boxes:
+                    if pg == 0:
+                        sx, sy, sw, sh = shrink_box(int(x), int(y), int(w), int(h))
+                        prob0[sy:sy + sh, sx:sx + sw] = 0.75
+                prob0 += np.float32(0.25) * np.random.default_rng(0).random((args.height, args.width), dtype=np.float32)
+            cb, cer_cpu = cpu_baseline(args, det_sd, rec_sd, images_u8[0], crops_all, texts, prob0)
             res["cpu_baseline"] = cb
             if cer_cpu is not None:
                 res["cer_vs_cpu_ref"] = round(cer_cpu["cer"], 5)
