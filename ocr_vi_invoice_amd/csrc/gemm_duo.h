@@ -197,6 +197,9 @@ __global__ __launch_bounds__(512, 2) void gemm_duo_kernel(const ConvParams p, co
             };
             auto blk = [&](auto BB) {
                 constexpr int b = decltype(BB)::value, cur = b & 1, nxt = cur ^ 1;
+                if (plan.dbg & 256) {   // (experiment) the SIMD partners alternate issue priority block by block
+                    if ((b & 1) == grp) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
+                }
                 // products: wL.xH, wH.xL, wH.xH (Mma<f16x2_t>::three), column blocks in pairs
                 mm(wL[0], xH[cur], acc[0][b]); mm(wL[1], xH[cur], acc[1][b]);
                 if constexpr (b + 2 < MI) xc[cur][0] = lds16(Ar + (b + 2) * 2048 + foa0);     // (xc[cur] was regrouped during block b - 1)
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(512, 2) void gemm_duo_kernel(const ConvParams p, co
             // Issue priority: the two waves of a SIMD are in different groups.  With equal priority the older wave wins every arbitration, runs
             // its step at full speed and then waits at the barrier while the younger one works through its step alone, gaps unfilled.  Group 0
             // takes priority in the first half of a step and group 1 in the second, so both progress side by side and fill each other's gaps.
-            const bool flip = !(plan.dbg & 64);
+            const bool flip = !(plan.dbg & 64) && !(plan.dbg & 256);
             if (flip) { if (grp == 0) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); }
             blk(IC<0>{}); blk(IC<1>{}); blk(IC<2>{}); blk(IC<3>{});
             if (flip) { if (grp == 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2); }
@@ -329,6 +332,10 @@ __global__ __launch_bounds__(512, 2) void gemm_duo_kernel(const ConvParams p, co
             });
         }
         etick(6);
+        // Issue priority: the epilogue's ~350 vector / memory instructions compete with the partner wave's MFMA stream for the SIMD's issue
+        // slots, and arbitration is by priority, then AGE -- at equal priority waves 4-7 (the younger half) got the leftovers: their epilogue
+        // steps took 19 k cycles against 3.3 k for waves 0-3 (phase stamps, K 1536), with everybody else waiting at the barrier.
+        if (plan.dbg & 128) __builtin_amdgcn_s_setprio(3);
         issue_all();
         etick(7);
         if constexpr (RESK != 0) {   // the residual loads are older than this step's NI (+ 4) DMA pieces only
@@ -339,6 +346,7 @@ __global__ __launch_bounds__(512, 2) void gemm_duo_kernel(const ConvParams p, co
             constexpr int j = decltype(J)::value, f = e * F + j;
             epi_frag(mt, IC<f>{}, J);
         });
+        __builtin_amdgcn_s_setprio(0);
     };
 
     // ---- prologue: the weight stage of step 0 (all waves) and the activation stages of steps 0 and 1 of group 0 (its waves; group 1's first
