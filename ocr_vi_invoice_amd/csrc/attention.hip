@@ -37,6 +37,17 @@ template <> __device__ __forceinline__ f32x4 mfma16<f16_t>(const uint4& a, const
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
+// two fp32 values -> their packed fp16 hi halves and packed fp16 lo halves (round to nearest even both): 4 vector instructions per pair.
+// (the conversions are left to the compiler -- v_cvt_pk_f16_f32 -- and not written as inline asm: `a` and `b` come straight from v_exp_f32,
+// and the wait state a transcendental result needs before a vector instruction reads it is only inserted for instructions hipcc can see)
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& H, unsigned& L) {
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+    H = __builtin_bit_cast(unsigned, __builtin_convertvector((f2v){a, b}, h2v));
+    const float la = fma_mix_lo(-1.0f, H, a), lb = fma_mix_hi(-1.0f, H, b);   // exact in fp32
+    L = __builtin_bit_cast(unsigned, __builtin_convertvector((f2v){la, lb}, h2v));
+}
+
 // MAXT = number of 16-key tiles held in registers; MASK = false when N == 16*MAXT exactly (480 / 240 / 80 tokens at 48x320 input):
 // then no key masking is generated at all.
 // NWV = waves per workgroup (they share the staged K / V^T): 8 for the fp32 480-key case, whose 123 KB of LDS allow one workgroup per CU --
@@ -175,14 +186,37 @@ __global__ __launch_bounds__(NWV * 64, (IsSplit<T>::value && MAXT <= 16 && NWV =
         // numbers; the row sum carries the same factor and cancels it in 1 / sum
         const float nm = -mx * c2 + (IsSplit<T>::value ? 12.0f : 0.0f);
         float sum = 0.f;
+        // (the 8-wave build at 16 masked key tiles sits at its 128-register cap: the packed form, which wants its operand pairs in adjacent
+        // registers, spills there -- it keeps the scalar form)
+        if constexpr (IsSplit<T>::value && !(MASK && MAXT == 16 && NWV == 8)) {
+            // the kernel is bound by vector issue (one v_exp_f32 and the hi / lo split per score against 1.5 MFMAs): the scale-and-shift and the
+            // row sum run as packed fp32 instructions (v_pk_fma_f32, v_pk_add_f32: two scores each)
+            typedef float f2v __attribute__((ext_vector_type(2)));
+            const f2v c2v = {c2, c2}, nmv = {nm, nm};
+            f2v sum2 = {0.f, 0.f};
 #pragma unroll
-        for (int t = 0; t < MAXT; ++t) {
+            for (int t = 0; t < MAXT; ++t) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                // exp2((s - max) * scale*log2e): one fma + raw v_exp_f32 (argument <= 0: no overflow; underflow flushes to 0)
-                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[t][r], c2, nm));
-                acc[t][r] = p;
-                if constexpr (sizeof(T) == 4) sum += p;
+                for (int h = 0; h < 2; ++h) {
+                    f2v e = __builtin_elementwise_fma((f2v){acc[t][2 * h], acc[t][2 * h + 1]}, c2v, nmv);
+                    e[0] = __builtin_amdgcn_exp2f(e[0]);
+                    e[1] = __builtin_amdgcn_exp2f(e[1]);
+                    sum2 += e;
+                    acc[t][2 * h] = e[0];
+                    acc[t][2 * h + 1] = e[1];
+                }
+            }
+            sum = sum2[0] + sum2[1];
+        } else {
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // exp2((s - max) * scale*log2e): one fma + raw v_exp_f32 (argument <= 0: no overflow; underflow flushes to 0)
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[t][r], c2, nm));
+                    acc[t][r] = p;
+                    if constexpr (sizeof(T) == 4) sum += p;
+                }
             }
         }
         // ---- O^T = V^T P^T
@@ -192,16 +226,17 @@ __global__ __launch_bounds__(NWV * 64, (IsSplit<T>::value && MAXT <= 16 && NWV =
 #pragma unroll
             for (int s = 0; s < (MAXT + 1) / 2; ++s) {       // 32 keys per step: the P chunks of tiles 2s and 2s + 1 form one (hi, lo) quartet pair
                 typedef typename Mma<T>::u4v U;
-                const float p0[4] = {acc[2 * s][0], acc[2 * s][1], acc[2 * s][2], acc[2 * s][3]};
-                const uint4 c0 = Chunk<T>::pack(p0);                   // keys 32 s + 4 g .. + 3 of query lr: [4 hi | 4 lo]
-                uint4 c1 = make_uint4(0, 0, 0, 0);                     // keys 32 s + 16 + 4 g .. + 3 (nothing past the last tile)
+                // the (hi, lo) quartets of P straight from the accumulators, two scores per conversion (what Chunk<T>::pack + regroup produce,
+                // bit for bit: hi = RNE(p), lo = RNE(p - hi)): keys 32 s + 4 g .. + 3 of query lr, then 32 s + 16 + 4 g .. + 3 (nothing past the last tile)
+                unsigned h0, h1, h2 = 0u, h3 = 0u, l0, l1, l2 = 0u, l3 = 0u;
+                split_pair(acc[2 * s][0], acc[2 * s][1], h0, l0);
+                split_pair(acc[2 * s][2], acc[2 * s][3], h1, l1);
                 if (2 * s + 1 < MAXT) {
                     const int t1 = 2 * s + 1 < MAXT ? 2 * s + 1 : 0;
-                    const float p1[4] = {acc[t1][0], acc[t1][1], acc[t1][2], acc[t1][3]};
-                    c1 = Chunk<T>::pack(p1);
+                    split_pair(acc[t1][0], acc[t1][1], h2, l2);
+                    split_pair(acc[t1][2], acc[t1][3], h3, l3);
                 }
-                U pH, pL;
-                Mma<T>::regroup(c0, c1, pH, pL);
+                const U pH = {h0, h1, h2, h3}, pL = {l0, l1, l2, l3};
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
                     const char* vr = Vtq + (dt * 16 + lr) * VS + 128 * s + 32 * g;   // the same keys of head-dim row 16 dt + lr, staged as (hi, lo) quartets

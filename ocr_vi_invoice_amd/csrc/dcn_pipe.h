@@ -20,14 +20,20 @@
 
 namespace ocrvi {
 
-template <typename T, int BN>
+// PROF (development only, -DOCRVI_RING_PROF_BUILD + OCRVI_RING_PROF=1): per wave half (waves 0-3 / 4-7) the shader-clock cycles spent in the tile's
+// geometry pass / waiting for own VMEM / at the barrier / issuing gathers and weight DMA / blending / ds_read + MFMA / in the epilogue, summed into p.out2.
+template <typename T, int BN, bool PROF = false>
 __global__ __launch_bounds__(512, 2) void dcn_pipe_kernel(const ConvParams p) {
     constexpr int EPC = TypeInfo<T>::EPC, BM = 128;     // elements per 16-byte chunk: 8 (16-bit types) or 4 (fp32)
     constexpr int CB = 8 * EPC;                         // channels per K-step (128 bytes): 64 or 32
     constexpr int WST = BN * 128, SLAB = BM * 128;
     constexpr int NI = BN / 32;            // 16-channel MFMA blocks per wave (BN / 2 channels)
     constexpr int GW = BN / 64;            // weight DMA instructions per wave per stage (BN / 8 pieces over 8 waves)
+#ifdef OCRVI_TIMING_DCN_ONEC                // (development, timing only: one corner load per item instead of four -- wrong results)
+    constexpr int GG = 2;
+#else
     constexpr int GG = 8;                  // gather loads per lane per step: 2 (row, chunk) items x 4 corners
+#endif
     static_assert(BN == 128 || BN == 256, "column tile");
     constexpr bool PERM = sizeof(T) == 2;               // 16-bit output: weight rows permuted so a lane ends with 8 consecutive channels
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -41,6 +47,26 @@ __global__ __launch_bounds__(512, 2) void dcn_pipe_kernel(const ConvParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int lr = lane & 15, g = lane >> 4;
+    long long tk[7] = {0, 0, 0, 0, 0, 0, 0}, t0 = 0;
+    if constexpr (PROF) t0 = clock64();
+    auto tick = [&](int k) {
+        if constexpr (PROF) {
+            const long long t = clock64();
+            tk[k] += t - t0;
+            t0 = t;
+        }
+    };
+    auto wait_bar = [&](auto NN) {   // counted wait, then the step's barrier
+        constexpr int N = decltype(NN)::value;
+        if constexpr (PROF) {
+            wait_vm_only<N>();
+            tick(1);
+            asm volatile("s_barrier" ::: "memory");
+            tick(2);
+        } else {
+            wait_vm_barrier<N>();
+        }
+    };
     const char* const xbase = uniform_ptr((const char*)p.x);
     const int rowb = p.Cin * (int)sizeof(T);                           // bytes per input pixel
     const int nk = 9 * (p.Cin_g / CB);
@@ -100,11 +126,18 @@ __global__ __launch_bounds__(512, 2) void dcn_pipe_kernel(const ConvParams p) {
                 const int xc0 = min(max(x0, 0), p.W - 1), xc1 = min(max(x1, 0), p.W - 1);
                 ov = ((unsigned)(img * p.H * p.W + yc0 * p.W + xc0) * (unsigned)rowb) | (unsigned)(xc1 - xc0) | ((unsigned)(yc1 - yc0) << 1);
             }
+#ifdef OCRVI_TIMING_DCN_NEAR   // (development, timing only: every sample reads its own output pixel's neighbourhood -- the gathers hit L1)
+            if (m >= 0) {
+                const int oh = min(oh0 + (row >> lw), p.OH - 1) * p.SH, ow = min(ow0 + (row & (PW - 1)), p.OW - 1) * p.SW;
+                ov = ((unsigned)(img * p.H * p.W + min(oh, p.H - 2) * p.W + min(ow, p.W - 2)) * (unsigned)rowb) | 3u;
+            }
+#endif
             Gw[i] = wv;
             Go[i] = ov;
         }
         __syncthreads();
         wait_vm_only<0>();  // nothing of this wave is in flight when the counted pipeline starts
+        tick(0);
 
         const char* const w_tile = uniform_ptr((const char*)p.w + (size_t)n0 * ldw_b);
         auto issue_w = [&](int ks) {  // weight stage ks -> ring slot ks % 3
@@ -130,9 +163,11 @@ __global__ __launch_bounds__(512, 2) void dcn_pipe_kernel(const ConvParams p) {
                 const unsigned o00 = (ov & ~3u) + coff, dxo = (ov & 1u) ? (unsigned)rowb : 0u, dyo = (ov & 2u) ? (unsigned)(rowb * p.W) : 0u;
                 S.w[it][0] = wv.x; S.w[it][1] = wv.y; S.w[it][2] = wv.z; S.w[it][3] = wv.w;
                 gload16s(S.c[it][0], xbase, o00);
+#ifndef OCRVI_TIMING_DCN_ONEC
                 gload16s(S.c[it][1], xbase, o00 + dxo);
                 gload16s(S.c[it][2], xbase, o00 + dyo);
                 gload16s(S.c[it][3], xbase, o00 + dyo + dxo);
+#endif
             }
         };
         auto blend = [&](int ks, GSet& S) {  // fp32 blend of step ks -> slab ks & 1
@@ -141,6 +176,9 @@ __global__ __launch_bounds__(512, 2) void dcn_pipe_kernel(const ConvParams p) {
             for (int it = 0; it < 2; ++it) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) bind16(S.c[it][q]);
+#ifdef OCRVI_TIMING_DCN_ONEC
+                S.c[it][1] = S.c[it][2] = S.c[it][3] = S.c[it][0];
+#endif
                 float acc[EPC], f[EPC];
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
@@ -219,15 +257,21 @@ __global__ __launch_bounds__(512, 2) void dcn_pipe_kernel(const ConvParams p) {
                 issue_w(1);
                 issue_gather(1, SA);
             }
+            tick(3);
             for (int s = 0; s < nk; ++s) {
                 // stage s has landed once everything but weights(s+1) and gathers(s+1) is done
-                if (s + 1 < nk) wait_vm_barrier<GG + GW>(); else wait_vm_barrier<0>();
+                if (s + 1 < nk) wait_bar(IC<GG + GW>{}); else wait_bar(IC<0>{});
                 if (s + 2 < nk) issue_w(s + 2);
+                tick(3);
                 mma(s);
+                tick(5);
                 if (s + 1 < nk) {
                     if (s + 2 < nk) wait_vm_only<GW>(); else wait_vm_only<0>();      // gathers(s+1): only weights(s+2) is younger
+                    tick(1);
                     blend(s + 1, SA);
+                    tick(4);
                     if (s + 2 < nk) issue_gather(s + 2, SA);
+                    tick(3);
                 }
             }
         } else {
@@ -242,14 +286,18 @@ __global__ __launch_bounds__(512, 2) void dcn_pipe_kernel(const ConvParams p) {
             }
             blend(0, SA);
             // ---- steady state, unrolled by two so the register sets have static names:  step s blends s + 1 and multiplies s
+            tick(3);
             auto step = [&](int s, GSet& Sblend, GSet& Snext) {
-                if (s + 1 < nk) wait_vm_barrier<GW>(); else wait_vm_barrier<0>();
+                if (s + 1 < nk) wait_bar(IC<GW>{}); else wait_bar(IC<0>{});
                 if (s + 2 < nk) {
                     issue_gather(s + 2, Snext);
                     issue_w(s + 2);
                 }
+                tick(3);
                 if (s + 1 < nk) blend(s + 1, Sblend);
+                tick(4);
                 mma(s);
+                tick(5);
             };
             for (int s = 0; s < nk; s += 2) {
                 step(s, SB, SA);          // blends s + 1 (set B), refills set A with s + 2
@@ -304,6 +352,11 @@ __global__ __launch_bounds__(512, 2) void dcn_pipe_kernel(const ConvParams p) {
                 }
             }
         }
+        tick(6);
+    }
+    if constexpr (PROF) {
+        if (lane == 0)
+            for (int k = 0; k < 7; ++k) atomicAdd((unsigned long long*)p.out2 + (wave >> 2) * 8 + k, (unsigned long long)tk[k]);
     }
 }
 
@@ -333,6 +386,40 @@ static int launch_dcn_pipe(const ConvParams& p_in, hipStream_t stream) {
     const int total = p.n_img * cdiv(p.OH, 128 >> best_lw) * cdiv(p.OW, 1 << best_lw) * (p.Np / bn);
     const int grid = cdiv(total, cdiv(total, std::min(total, n_cu)));   // one persistent workgroup per CU, equal tile counts
     const int smem = 3 * bn * 128 + 2 * 128 * 128 + 9 * 128 * 20;
+#ifdef OCRVI_RING_PROF_BUILD
+    static const bool prof = getenv("OCRVI_RING_PROF") && atoi(getenv("OCRVI_RING_PROF"));
+    if (prof) {  // development aid: cycle breakdown per phase and wave half, printed per launch (synchronises)
+        static unsigned long long* dbuf = nullptr;
+        if (!dbuf) OCRVI_HIP(hipMalloc((void**)&dbuf, 128));
+        OCRVI_HIP(hipMemsetAsync(dbuf, 0, 128, stream));
+        ConvParams q = p;
+        q.out2 = dbuf;
+        if (wide) {
+            auto k = dcn_pipe_kernel<T, 256, true>;
+            OCRVI_TRY(ensure_max_smem((const void*)k, smem));
+            hipLaunchKernelGGL(k, dim3(grid), dim3(512), smem, stream, q);
+        } else {
+            auto k = dcn_pipe_kernel<T, 128, true>;
+            OCRVI_TRY(ensure_max_smem((const void*)k, smem));
+            hipLaunchKernelGGL(k, dim3(grid), dim3(512), smem, stream, q);
+        }
+        unsigned long long h[16];
+        OCRVI_HIP(hipMemcpyAsync(h, dbuf, 128, hipMemcpyDeviceToHost, stream));
+        OCRVI_HIP(hipStreamSynchronize(stream));
+        const int nk = 9 * (p.Cin_g / (int)(128 / sizeof(T)));
+        const double tiles_per_wg = (double)total / grid;
+        for (int hf = 0; hf < 2; ++hf) {
+            const double w = 4.0 * grid;
+            const unsigned long long* v = h + 8 * hf;
+            double tot = 0;
+            for (int k = 0; k < 7; ++k) tot += (double)v[k];
+            fprintf(stderr, "dcn_pipe BN%d Cin %d %dx%d s%d grid %d tiles/wg %.1f nk %d waves %d-%d: cycles/wave geometry %.0f vm-wait %.0f barrier %.0f issue %.0f blend %.0f mma %.0f epilogue %.0f total %.0f | per step: wait %.0f barrier %.0f issue %.0f blend %.0f mma %.0f\n",
+                    bn, p.Cin_g, p.H, p.W, p.SH, grid, tiles_per_wg, nk, 4 * hf, 4 * hf + 3, v[0] / w, v[1] / w, v[2] / w, v[3] / w, v[4] / w, v[5] / w, v[6] / w, tot / w,
+                    v[1] / w / (tiles_per_wg * nk), v[2] / w / (tiles_per_wg * nk), v[3] / w / (tiles_per_wg * nk), v[4] / w / (tiles_per_wg * nk), v[5] / w / (tiles_per_wg * nk));
+        }
+        return OCRVI_OK;
+    }
+#endif
     if (wide) {
         auto k = dcn_pipe_kernel<T, 256>;
         OCRVI_TRY(ensure_max_smem((const void*)k, smem));

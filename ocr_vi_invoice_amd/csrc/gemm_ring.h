@@ -180,7 +180,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gemm_ring_kernel(const ConvPa
                 a_off[i] = (unsigned)((img * p.H + oh * p.SH) * p.W + ow * p.SW) * (unsigned)lda_b + chunk * 16;
             }
         } else {
+#ifdef OCRVI_TIMING_RING_AWRAP   // (development, timing only: every row tile reads one of four -- the activations stay in L2)
+            a_tile = uniform_ptr(A + (size_t)(mt & 3) * BM * lda_b);
+#else
             a_tile = uniform_ptr(A + (size_t)mt * BM * lda_b);
+#endif
             const int last = p.M - 1 - mt * BM;                   // last valid row of this tile
 #pragma unroll
             for (int i = 0; i < NA; ++i) a_off[i] = (unsigned)(min((i * NW + wave) * 8 + prow, last) * lda_b + chunk * 16);
@@ -364,7 +368,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gemm_ring_kernel(const ConvPa
 #pragma unroll
         for (int j = 0; j < SPS; ++j) {
             const int m = pmt * BM + wm * TM + (q0 + j) * 16 + lr;
+#ifdef OCRVI_TIMING_RING_OWRAP   // (development, timing only: the output rows wrap at 2048 -- the stores stay in L2)
+            const unsigned row_b = m < p.M ? ((unsigned)(m & 2047) * (unsigned)p.ldo + (unsigned)(p.out_coff + nb)) * (unsigned)osz_b : OOB;
+#else
             const unsigned row_b = m < p.M ? ((unsigned)m * (unsigned)p.ldo + (unsigned)(p.out_coff + nb)) * (unsigned)osz_b : OOB;
+#endif
             if constexpr (F32O) {
 #pragma unroll
                 for (int a = 0; a < NI; ++a) {
