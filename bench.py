@@ -664,6 +664,10 @@ def roofline_of(prof, dtype):
     if dtype == "f16x2" and r["bound"] == "mfma":
         r.update({"peak": round(r["peak"], 1), "peak_note": "2500 TFLOP/s dense 16-bit MFMA / 3 partial products per product",
                   "executed_16bit_mfma_tflops": round(3 * r["achieved"], 1), "frac_of_fp32_mfma_peak": round(r["achieved"] / 157.3, 4)})
+    # the same launches against the OTHER roof (a GEMM on 4-byte f16x2 elements sits close to the ridge: both fractions are of interest)
+    r["hbm_frac_algorithmic"] = round(d["bytes"] / (d["ms"] / 1e3) / 1e9 / PEAK_HBM_GBS, 4)
+    if traffic:
+        r["hbm_frac_traffic"] = round(traffic * d["launches"] / (d["ms"] / 1e3) / 1e9 / PEAK_HBM_GBS, 4)
     r.update({"traffic": traffic, "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"], 1), "launches": d["launches"],
               "avg_ms": round(d["ms"] / d["launches"], 4), "algorithmic_flops_per_launch": round(d["flops"] / d["launches"], 1),
               "timed_by": "HIP events on the launch stream around every launch, one sequential eager pass after the timed region"})

@@ -218,6 +218,12 @@ int ocrvi_test_gemm(int device, int dtype, const float* a, const float* weight_h
                     int K, int N, int act, int res_post, int out_f32, float* out, int iters, float* avg_ms);
 /* Multi-head self-attention on a packed qkv tensor [B, N, 3*heads*32] float32 (layout of
  * qkv.reshape(B,N,3,heads,32), svtrv2.py:80) -> out [B, N, heads*32] float32 (svtrv2.py:82-85). */
+/* The detector's stem: conv 7x7 stride 2 pad 3 (3 -> 64 channels) + bias + ReLU + max-pool 3x3 stride 2 pad 1 (torchvision resnet50's
+ * conv1 / bn1 / relu / maxpool with BN folded, backbone.py:34).  fused != 0: the one-kernel f16x2 form (dtype must be 3), else the two
+ * kernels of the other compute types.  x float32 NCHW device [N,3,H,W] (H, W multiples of 4); weight float32 host [64,3,7,7]; bias float32
+ * host [64]; out float32 NCHW device [N,64,H/4,W/4].  Test hook: allocates and synchronises internally. */
+int ocrvi_test_stem_pool(int device, int dtype, const float* x, const float* weight_host, const float* bias_host, int N, int H, int W, int fused,
+                         float* out, int iters, float* avg_ms);
 int ocrvi_test_attention(int device, int dtype, const float* qkv, int B, int N, int heads, float* out, int iters,
                          float* avg_ms);
 

@@ -23,7 +23,7 @@ EXPORTS = [
     "ocrvi_rec_create", "ocrvi_rec_destroy", "ocrvi_rec_workspace_bytes", "ocrvi_rec_forward", "ocrvi_rec_debug_features",
     "ocrvi_ctc_greedy", "ocrvi_normalize_u8", "ocrvi_resize_u8", "ocrvi_crop_resize_normalize", "ocrvi_db_postprocess", "ocrvi_db_boxes_batch",
     "ocrvi_unclip_polygon", "ocrvi_db_components_workspace_bytes", "ocrvi_db_components", "ocrvi_db_boxes_batch_sparse",
-    "ocrvi_test_deform_conv", "ocrvi_test_offset_conv", "ocrvi_test_conv", "ocrvi_test_gemm", "ocrvi_test_attention", "ocrvi_test_mlp", "ocrvi_test_pack_f16x2",
+    "ocrvi_test_deform_conv", "ocrvi_test_offset_conv", "ocrvi_test_conv", "ocrvi_test_gemm", "ocrvi_test_attention", "ocrvi_test_mlp", "ocrvi_test_stem_pool", "ocrvi_test_pack_f16x2",
     "ocrvi_prof_enable", "ocrvi_prof_reset", "ocrvi_prof_report",
     "ocrvi_det_status", "ocrvi_rec_status", "ocrvi_range_reset", "ocrvi_range_flag",
 ]
@@ -88,6 +88,7 @@ def load() -> C.CDLL:
     lib.ocrvi_test_conv.argtypes = [i32, i32, f32p, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32p, i32,
                                     C.POINTER(C.c_float)]
     lib.ocrvi_test_gemm.argtypes = [i32, i32, f32p, vp, vp, f32p, i32, i32, i32, i32, i32, i32, f32p, i32, C.POINTER(C.c_float)]
+    lib.ocrvi_test_stem_pool.argtypes = [i32, i32, f32p, vp, vp, i32, i32, i32, i32, f32p, i32, C.POINTER(C.c_float)]
     lib.ocrvi_test_attention.argtypes = [i32, i32, f32p, i32, i32, i32, f32p, i32, C.POINTER(C.c_float)]
     lib.ocrvi_test_mlp.argtypes = [i32, i32, f32p, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32p, i32, C.POINTER(C.c_float)]
     lib.ocrvi_test_pack_f16x2.argtypes = [f32p, sz, vp, C.POINTER(C.c_float)]

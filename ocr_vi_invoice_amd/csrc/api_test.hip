@@ -117,6 +117,38 @@ extern "C" int ocrvi_test_deform_conv(int device, int dtype, const float* x, con
     return OCRVI_OK;
 }
 
+extern "C" int ocrvi_test_stem_pool(int device, int dtype, const float* x, const float* weight_host, const float* bias_host, int N, int H, int W,
+                                    int fused, float* out, int iters, float* avg_ms) {
+    OCRVI_CHECK(x && weight_host && bias_host && out && N > 0 && H >= 8 && W >= 8 && H % 4 == 0 && W % 4 == 0, OCRVI_EINVAL, "test_stem_pool: bad argument");
+    OCRVI_CHECK(!fused || dtype == OCRVI_F16X2, OCRVI_EINVAL, "test_stem_pool: the fused kernel is the f16x2 form");
+    OCRVI_HIP(hipSetDevice(device));
+    Scratch sc;
+    OCRVI_TRY(sc.init());
+    DeviceStore st;
+    ConvLayer L;
+    PackedConv pc = pack_conv(weight_host, bias_host, 64, 3, 7, 7, 1, AM_ROWS, dtype);
+    OCRVI_TRY(upload_packed(st, pc, AM_ROWS, &L));
+    const int Hp = H + 6, Wp = W + 8;
+    void *xp = nullptr, *sn = nullptr, *yn = nullptr;
+    OCRVI_TRY(sc.alloc((size_t)N * Hp * Wp * 4 * dtype_size(dtype), &xp));
+    OCRVI_TRY(sc.alloc((size_t)N * (H / 2) * (W / 2) * 64 * dtype_size(dtype), &sn));
+    OCRVI_TRY(sc.alloc((size_t)N * (H / 4) * (W / 4) * 64 * dtype_size(dtype), &yn));
+    OCRVI_TRY(k_nchw3_to_nhwc4_pad(dtype, x, xp, N, H, W, 3, 3, Hp, Wp, sc.s));
+    Runner r(dtype, sc.s, (void*)256, 0);
+    Tensor tx; tx.p = xp; tx.n = N; tx.h = Hp; tx.w = Wp; tx.c = 4;
+    Tensor ts; ts.p = sn; ts.n = N; ts.h = H / 2; ts.w = W / 2; ts.c = 64;
+    ConvOpts o;
+    o.sh = o.sw = 2; o.pad = 3; o.act = ACT_RELU; o.Hp = Hp; o.Wp = Wp;
+    OCRVI_TRY(timed(sc, iters, avg_ms, [&]() -> int {
+        if (fused) return k_stem_pool(dtype, xp, L.w, L.bias, L.wscale, yn, N, H, W, Hp, Wp, sc.s);
+        OCRVI_TRY(conv(r, L, tx, ts, o));
+        return k_maxpool3x3s2(dtype, sn, yn, N, H / 2, W / 2, 64, sc.s);
+    }));
+    OCRVI_TRY(k_nhwc_to_nchw_f32(dtype, yn, out, N, H / 4, W / 4, 64, 64, 0, sc.s));
+    OCRVI_HIP(hipStreamSynchronize(sc.s));
+    return OCRVI_OK;
+}
+
 extern "C" int ocrvi_test_conv(int device, int dtype, const float* x, const float* weight_host, const float* bias_host, int N, int C,
                                int H, int W, int Co, int ksize, int sh, int sw, int groups, int act, float* out, int iters, float* avg_ms) {
     OCRVI_CHECK(x && weight_host && out && (ksize == 1 || ksize == 3) && groups >= 1 && C % groups == 0 && Co % groups == 0, OCRVI_EINVAL,

@@ -130,14 +130,21 @@ static int det_run(ocrvi_det* h, Runner& r, const float* x, int N, int H, int W,
     Tensor xpad = r.alloc(N, Hp, Wp, 4);
     if (!r.dry()) OCRVI_TRY(k_nchw3_to_nhwc4_pad(dt, x, xpad.p, N, H, W, 3, 3, Hp, Wp, r.stream));
     // ---- stem: conv 7x7/2 + BN + ReLU, maxpool 3x3/2 (torchvision resnet50 via backbone.py:34)
-    Tensor s = r.alloc(N, H / 2, W / 2, 64);
-    {
-        ConvOpts o;
-        o.sh = o.sw = 2; o.pad = 3; o.act = ACT_RELU; o.Hp = Hp; o.Wp = Wp;
-        OCRVI_TRY(conv(r, h->stem, xpad, s, o));
+    Tensor cur;
+    if (stem_pool_eligible(dt, h->stem.N_g, h->stem.Kp, h->stem.KH, H, W)) {
+        // f16x2: one kernel; the half-resolution 64-channel map (the detector's largest tensor) is never written (stem_pool.hip)
+        cur = r.alloc(N, H / 4, W / 4, 64);
+        if (!r.dry()) OCRVI_TRY(k_stem_pool(dt, xpad.p, h->stem.w, h->stem.bias, h->stem.wscale, cur.p, N, H, W, Hp, Wp, r.stream));
+    } else {
+        Tensor s = r.alloc(N, H / 2, W / 2, 64);
+        {
+            ConvOpts o;
+            o.sh = o.sw = 2; o.pad = 3; o.act = ACT_RELU; o.Hp = Hp; o.Wp = Wp;
+            OCRVI_TRY(conv(r, h->stem, xpad, s, o));
+        }
+        cur = r.alloc(N, H / 4, W / 4, 64);
+        if (!r.dry()) OCRVI_TRY(k_maxpool3x3s2(dt, s.p, cur.p, N, H / 2, W / 2, 64, r.stream));
     }
-    Tensor cur = r.alloc(N, H / 4, W / 4, 64);
-    if (!r.dry()) OCRVI_TRY(k_maxpool3x3s2(dt, s.p, cur.p, N, H / 2, W / 2, 64, r.stream));
     // ---- layers 1..4.  Block outputs ping-pong between two slots per layer (sized for the layer's output); the last block of a
     // layer writes a fresh buffer that stays live as the c2..c5 tap (backbone.py:56-60).  Temporaries of a block are released
     // when it ends, so a chunk of 16 pages keeps ~4 GB less live than with one buffer per block.

@@ -9,6 +9,11 @@ namespace ocrvi {
 int k_nchw3_to_nhwc4_pad(int dtype, const float* x, void* y, int N, int H, int W, int pad_t, int pad_l, int Hp, int Wp, hipStream_t s);
 // MaxPool2d(3, stride 2, pad 1) on NHWC T (torchvision resnet stem, backbone.py:34).
 int k_maxpool3x3s2(int dtype, const void* x, void* y, int N, int H, int W, int C, hipStream_t s);
+// f16x2: the detector's stem conv 7x7 / 2 (+ folded BN, ReLU) and this max-pool fused (stem_pool.hip).  xpad: the stem conv's padded NHWC4
+// input [N][Hp][Wp][4]; w / bias / wscale: the stem's packed weights (pack_conv, AM_ROWS); y: [N][H / 4][W / 4][64].
+bool stem_pool_eligible(int dtype, int cout, int Kp, int KH, int H, int W);
+int k_stem_pool(int dtype, const void* xpad, const void* w, const float* bias, float wscale, void* y, int N, int H, int W, int Hp, int Wp,
+                hipStream_t s);
 // LayerNorm over the last dim (eps 1e-5, svtrv2.py:93,95,446).  x is f32 or T, out is f32 or T.
 int k_layernorm(int dtype, const void* x, int x_f32, void* out, int out_f32, const float* gamma, const float* beta, int rows, int D,
                 hipStream_t s);

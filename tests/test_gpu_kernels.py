@@ -406,3 +406,67 @@ def test_offset_conv_kernel(case, dt):
     tol = 2e-5 if dt in EXACT else 2e-3      # fp32 accumulation of exactly representable products; the sigmoid compresses further
     err = float((out[..., :27] - ref).abs().max())
     assert err < tol, err
+
+
+# ---- the detector's stem: conv 7x7 / 2 + bias + ReLU + max-pool 3x3 / 2 (backbone.py:34 with BN folded)
+def _run_stem_pool(x, w, b, dt, fused, iters=0):
+    L = _lib()
+    lib = L.load()
+    N, _, H, W = x.shape
+    xd = x.cuda().contiguous()
+    out = torch.empty((N, 64, H // 4, W // 4), device="cuda")
+    ms = C.c_float(0)
+    L.check(lib.ocrvi_test_stem_pool(0, DT[dt], xd.data_ptr(), np.ascontiguousarray(w.numpy()).ctypes.data, np.ascontiguousarray(b.numpy()).ctypes.data,
+                                     N, H, W, int(fused), out.data_ptr(), iters, C.byref(ms)))
+    return out.cpu(), ms.value
+
+
+def _stem_ref(x, w, b):
+    y = F.relu(F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=3))
+    return F.max_pool2d(y, 3, 2, 1).float()
+
+
+# image sizes: one tile; partial tiles on both axes (9 x 13 and 33 x 22 pooled pixels against the 8 x 7 patch); several images
+@pytest.mark.parametrize("N,H,W", [(1, 32, 28), (2, 36, 52), (1, 132, 88), (3, 64, 96)])
+def test_stem_pool_fused_kernel(N, H, W):
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(N, 3, H, W, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) / 147 ** 0.5
+    b = torch.randn(64, generator=g) * 0.5
+    ref = _stem_ref(x, w, b)
+    fused, _ = _run_stem_pool(x, w, b, "f16x2", True)
+    assert _rel_err(fused, ref) < TOL["f16x2"], _rel_err(fused, ref)
+    plain, _ = _run_stem_pool(x, w, b, "f16x2", False)
+    assert _rel_err(plain, ref) < TOL["f16x2"]
+    # the two forms round differently (three vs four partial products) but agree to the mode's own accuracy
+    assert _rel_err(fused, plain) < TOL["f16x2"]
+
+
+def test_stem_pool_fused_kernel_borders_are_pool_padding_not_zeros():
+    """All conv outputs negative before the ReLU -> 0 everywhere after it; with a positive bias only at the border-free interior the max-pool's
+    -inf padding (not a zero) must be what surrounds the map: a strictly positive map stays strictly positive at the borders."""
+    x = torch.zeros(1, 3, 32, 28)
+    w = torch.zeros(64, 3, 7, 7)
+    b = torch.full((64,), 0.25)
+    out, _ = _run_stem_pool(x, w, b, "f16x2", True)
+    assert torch.equal(out, torch.full_like(out, 0.25))
+
+
+def test_stem_pool_fused_kernel_full_size_equals_the_two_kernel_form():
+    g = torch.Generator().manual_seed(12)
+    x = torch.rand(2, 3, 960, 1280, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) / 147 ** 0.5
+    b = torch.randn(64, generator=g) * 0.1
+    fused, _ = _run_stem_pool(x, w, b, "f16x2", True)
+    plain, _ = _run_stem_pool(x, w, b, "f16x2", False)
+    assert _rel_err(fused, plain) < TOL["f16x2"], _rel_err(fused, plain)
+
+
+def test_stem_pool_fused_rejects_other_types():
+    L = _lib()
+    x = torch.zeros(1, 3, 32, 32, device="cuda")
+    out = torch.empty(1, 64, 8, 8, device="cuda")
+    w = np.zeros((64, 3, 7, 7), np.float32)
+    b = np.zeros(64, np.float32)
+    with pytest.raises(ValueError):
+        L.check(L.load().ocrvi_test_stem_pool(0, DT["f16"], x.data_ptr(), w.ctypes.data, b.ctypes.data, 1, 32, 32, 1, out.data_ptr(), 0, None))

@@ -26,7 +26,7 @@ def test_ring_gemm_isa_keeps_the_vmcnt_protocol(src, nmin):
 
 
 @pytest.mark.skipif(not shutil.which("/opt/rocm/bin/hipcc"), reason="hipcc not available")
-@pytest.mark.parametrize("src", ["conv_bf16.hip", "conv_f16.hip", "conv_f32.hip", "conv_f16x2.hip", "mlp_fused.hip", "attention.hip"])
+@pytest.mark.parametrize("src", ["conv_bf16.hip", "conv_f16.hip", "conv_f32.hip", "conv_f16x2.hip", "mlp_fused.hip", "attention.hip", "stem_pool.hip"])
 def test_no_mfma_kernel_of_the_library_spills(src):
     """dcn_pipe, offs_conv and mlp_fused count their vmcnt by hand like the ring GEMM: a spill there is an uncounted VMEM operation.  In the
     other MFMA kernels (conv_gemm, gconv32, attention) it is a performance bug.  None may contain a scratch instruction."""

@@ -61,7 +61,7 @@ def touches_before_wait(body, start, dst):
     return hits
 
 
-ALL_SOURCES = ["conv_bf16.hip", "conv_f16.hip", "conv_f32.hip", "conv_f16x2.hip", "duo_f16x2.hip", "mlp_fused.hip", "attention.hip"]
+ALL_SOURCES = ["conv_bf16.hip", "conv_f16.hip", "conv_f32.hip", "conv_f16x2.hip", "duo_f16x2.hip", "mlp_fused.hip", "attention.hip", "stem_pool.hip"]
 _ASM = {}
 
 
@@ -117,7 +117,7 @@ def check(src):
 # Every other MFMA kernel of the library: no scratch instruction at all (a spill inside dcn_pipe / offs_conv / mlp_fused would be an
 # uncounted VMEM operation in a hand-counted vmcnt protocol; anywhere else it is a performance bug).
 OTHER_KERNELS = ["_ZN5ocrvi15dcn_pipe_kernel", "_ZN5ocrvi16offs_conv_kernel", "_ZN5ocrvi16mlp_fused_kernel", "_ZN5ocrvi16conv_gemm_kernel",
-                 "_ZN5ocrvi14gconv32_kernel", "_ZN5ocrvi16attention_kernel", "_ZN5ocrvi18attention16_kernel"]
+                 "_ZN5ocrvi14gconv32_kernel", "_ZN5ocrvi16attention_kernel", "_ZN5ocrvi18attention16_kernel", "_ZN5ocrvi16stem_pool_kernel"]
 
 
 def check_duo(src="duo_f16x2.hip"):
