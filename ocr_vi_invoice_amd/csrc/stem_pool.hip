@@ -5,8 +5,9 @@
 //
 // One persistent workgroup per CU (8 waves).  A tile is an 8 x 7 patch of POOLED pixels = a 17 x 15 patch of conv pixels (255: sixteen
 // 16-pixel MFMA blocks, two per wave) = a 39 x 36 patch of the zero-padded NHWC4 input (k_nchw3_to_nhwc4_pad):
-//   1. the tile's input patch, fetched into registers while the previous tile computed, goes to LDS            (24 KB)
-//   2. the next tile's patch loads are issued
+//   1. (during the previous tile's pooling pass) the tile's input patch, fetched into registers a tile earlier, goes to LDS as (hi, lo)
+//      quartets (25 KB)
+//   2. (same place) the loads of the patch after it are issued
 //   3. conv as an implicit GEMM: K-step r = filter row r = 8 consecutive input pixels x 4 channels (pack_conv's AM_ROWS order), so a
 //      lane's 8 k-slots are two adjacent 16-byte pixels of the patch; the 64 x 224 weights stay in LDS for the whole launch (57 KB, staged
 //      once in the (hi, lo) quartet form the three-product MFMAs consume); 168 MFMAs per wave
@@ -14,7 +15,7 @@
 //   5. 3 x 3 max over the staging, packed to f16x2 (range-checked), stored: 56 pixels x 256 B
 // A pooled row needs conv rows 2 y - 1 .. 2 y + 1, so neighbouring tiles recompute one conv row / column of halo: 255 conv pixels per
 // 224 useful ones (14 % more MFMAs, still a small kernel) -- the price of no inter-tile exchange.
-#include "conv_gemm.h"
+#include "gemm_ring.h"
 #include "kernels.h"
 
 namespace ocrvi {
@@ -29,7 +30,14 @@ constexpr int SP_NCH = SP_IR * SP_IC;                     // 1404 16-byte pixels
 constexpr int SP_PRE = (SP_NCH + 511) / 512;              // prefetch registers (uint4) per thread: 3
 constexpr int SP_KS = 7;                                  // K-steps = filter rows
 constexpr int SP_W_BYTES = SP_KS * 64 * 128;              // 57344
-constexpr int SP_P_BYTES = SP_PRE * 512 * 16;              // 24576: every thread moves SP_PRE pixels, the surplus ones land behind the patch
+// LDS image of the patch, in 16-byte units: input row rho at (rho >> 1) * 79 + (rho & 1) * 36; inside a row 18 units of hi quartets (unit q =
+// the hi halves of pixels 2 q and 2 q + 1: what a lane's MFMA operand takes, a lane always starts at an even pixel) and 18 of lo quartets.
+// The row-pair stride of 79 = 15 (mod 16) makes the 16 lanes of a read conflict-free although every 16-pixel block spans two conv rows
+// (15 pixels each): the pixels after the row break continue in the next bank group (simulated with the gfx950 lane-group rule: 4.25
+// LDS cycles per ds_read_b128 against 11 for plain [row][36 pixels] rows).
+constexpr int SP_PAIR = 79, SP_ODD = 36, SP_LO = 18;
+constexpr int SP_P_UNITS = ((SP_IR - 1) >> 1) * SP_PAIR + SP_ODD + 2 * SP_LO;   // 1573 >= the last unit + 1
+constexpr int SP_P_BYTES = ((SP_P_UNITS * 16 + 255) / 256) * 256;
 constexpr int SP_S_BYTES = 256 * 64 * 4;                  // 65536
 constexpr int SP_SMEM = SP_W_BYTES + SP_P_BYTES + SP_S_BYTES;
 static_assert(SP_NPX <= 256 && SP_NPX > 240, "sixteen MFMA blocks");
@@ -39,7 +47,7 @@ static_assert(SP_NPX <= 256 && SP_NPX > 240, "sixteen MFMA blocks");
 // y [N][OH][OW][64] f16x2 with OH = H / 4, OW = W / 4 (H, W = the image; the conv map is H / 2 x W / 2)
 __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const char* __restrict__ xpad, const char* __restrict__ w, const float* __restrict__ bias,
                                                           float wscale, char* __restrict__ y, int N, int CH, int CW, int OH, int OW, int Hp,
-                                                          int Wp, int tyN, int txN) {
+                                                          int Wp, int tyN, int txN, int dbg, unsigned long long* __restrict__ prof) {
     typedef f16x2_t T;
     typedef Mma<T>::u4v U;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -83,6 +91,15 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const char* __restric
         return *(const uint4*)(xpad + (((size_t)img * Hp + iy) * Wp + ix) * 16);
     };
 
+    auto put = [&](int k, const uint4& v) {   // pixel tid + 512 k of the patch -> its hi / lo quartet halves
+        const int idx = tid + 512 * k;
+        if (idx < SP_NCH) {
+            const int pr = idx / SP_IC, pc = idx - pr * SP_IC;
+            char* d = Ps + ((pr >> 1) * SP_PAIR + (pr & 1) * SP_ODD + (pc >> 1)) * 16 + (pc & 1) * 8;
+            *(uint2*)d = make_uint2(v.x, v.y);
+            *(uint2*)(d + SP_LO * 16) = make_uint2(v.z, v.w);
+        }
+    };
     // this wave's two MFMA blocks: conv pixel p = 16 blk + lr -> (i, j) of the 17 x 15 patch; patch byte offset of its first input pixel
     int a_off[2];
     bool dup[2];
@@ -91,7 +108,7 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const char* __restric
         const int p0 = (wave * 2 + b) * 16 + lr, p = min(p0, SP_NPX - 1);
         dup[b] = p0 >= SP_NPX;
         const int i = p / SP_CC, j = p - i * SP_CC;
-        a_off[b] = (2 * i * SP_IC + 2 * j + 2 * g) * 16;
+        a_off[b] = (i * SP_PAIR + j + g) * 16;          // hi quartet of input pixels 2 (j + g), 2 (j + g) + 1 of input row 2 i
     }
     const int swb = swz128(lr);
     const int fob0 = ((2 * g) ^ swb) << 4, fob1 = ((2 * g + 1) ^ swb) << 4;
@@ -100,51 +117,84 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const char* __restric
     for (int a = 0; a < 4; ++a) bv[a] = *(const float4*)(bias + 16 * a + 4 * g);
     unsigned long long range_mask = 0;
 
+    // Two barriers per tile: [MFMAs of tile t from the patch, results -> staging] | A | [patch of tile t + 1 -> LDS, loads of tile t + 2's
+    // patch issued, max-pool of tile t from the staging -> global] | B.  (A: every wave is done reading the patch and writing the staging;
+    // B: the next patch is complete and the staging is free.)
+    long long tk[6] = {0, 0, 0, 0, 0, 0}, tk0 = 0;   // (OCRVI_STEM_DBG & 8: shader-clock cycles per phase, summed over the waves into prof[])
+    auto tick = [&](int k) {
+        if (dbg & 8) {
+            const long long c = clock64();
+            tk[k] += c - tk0;
+            tk0 = c;
+        }
+    };
     int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int G = (int)gridDim.x;
     {
         const int tf = min(t, total - 1);
         pre0 = fetch1(tf, 0); pre1 = fetch1(tf, 1); pre2 = fetch1(tf, 2);
+        put(0, pre0);
+        put(1, pre1);
+        put(2, pre2);
+        const int tn = min(t + G, total - 1);
+        pre0 = fetch1(tn, 0); pre1 = fetch1(tn, 1); pre2 = fetch1(tn, 2);
     }
-    for (; t < total; t += gridDim.x) {
+    __syncthreads();   // (also: the weights are in LDS)
+    if (dbg & 8) tk0 = clock64();
+    for (; t < total; t += G) {
         int img, py0, px0;
         tile_of(t, img, py0, px0);
-        __syncthreads();   // the previous tile is done with the patch and the staging (first pass: the weights are in LDS)
-        *(uint4*)(Ps + tid * 16) = pre0;
-        *(uint4*)(Ps + (tid + 512) * 16) = pre1;
-        *(uint4*)(Ps + (tid + 1024) * 16) = pre2;
-        __syncthreads();
-        {   // the next tile's patch (the last tile fetches itself again: no branch around the loads)
-            const int tn = min(t + (int)gridDim.x, total - 1);
-            pre0 = fetch1(tn, 0); pre1 = fetch1(tn, 1); pre2 = fetch1(tn, 2);
-        }
 
         // ---- conv: 7 K-steps x (2 pixel blocks x 4 channel blocks) x 3 products
         f32x4 acc[4][2];
 #pragma unroll
         for (int a = 0; a < 4; ++a) acc[a][0] = acc[a][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // (software-pipelined by hand: the 12 fragment reads of filter row r + 1 are issued before the 24 MFMAs of row r -- left to itself
+        // hipcc reads every weight fragment right in front of its first MFMA and waits for it, ~5 exposed LDS round trips per row)
+        if (!(dbg & 2)) {    // (OCRVI_STEM_DBG, development, wrong results: 1 no pooling pass, 2 no MFMA phase, 4 no staging writes)
+            U xH[2][2], xL[2][2], wH[2][4], wL[2][4];
+            auto load_row = [&](auto R, auto S) {
+                constexpr int r = decltype(R)::value, sl = decltype(S)::value;
 #pragma unroll
-        for (int r = 0; r < SP_KS; ++r) {
-            U xH[2], xL[2];
+                for (int b = 0; b < 2; ++b) {
+                    const char* ap = Ps + a_off[b] + ((r >> 1) * SP_PAIR + (r & 1) * SP_ODD) * 16;
+                    const uint4 h = *(const uint4*)ap, l = *(const uint4*)(ap + SP_LO * 16);
+                    xH[sl][b] = (U){h.x, h.y, h.z, h.w};
+                    xL[sl][b] = (U){l.x, l.y, l.z, l.w};
+                }
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const char* ap = Ps + a_off[b] + r * (SP_IC * 16);
-                Mma<T>::regroup(*(const uint4*)ap, *(const uint4*)(ap + 16), xH[b], xL[b]);
-            }
+                for (int a = 0; a < 4; ++a) {
+                    const char* wr = Ws + (r * 64 + 16 * a + lr) * 128;
+                    const uint4 h = *(const uint4*)(wr + fob0), l = *(const uint4*)(wr + fob1);
+                    wH[sl][a] = (U){h.x, h.y, h.z, h.w};
+                    wL[sl][a] = (U){l.x, l.y, l.z, l.w};
+                }
+            };
+            auto mma_row = [&](auto S) {
+                constexpr int sl = decltype(S)::value;
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const char* wr = Ws + (r * 64 + 16 * a + lr) * 128;
-                const uint4 h = *(const uint4*)(wr + fob0), l = *(const uint4*)(wr + fob1);
-                const U wH = {h.x, h.y, h.z, h.w}, wL = {l.x, l.y, l.z, l.w};
-                Mma<T>::three(wH, wL, xH[0], xL[0], acc[a][0]);
-                Mma<T>::three(wH, wL, xH[1], xL[1], acc[a][1]);
-            }
+                for (int a = 0; a < 4; ++a) {
+                    Mma<T>::three(wH[sl][a], wL[sl][a], xH[sl][0], xL[sl][0], acc[a][0]);
+                    Mma<T>::three(wH[sl][a], wL[sl][a], xH[sl][1], xL[sl][1], acc[a][1]);
+                }
+            };
+            auto row = [&](auto R) {
+                constexpr int r = decltype(R)::value;
+                if constexpr (r + 1 < SP_KS) load_row(IC<r + 1>{}, IC<(r + 1) & 1>{});
+                __builtin_amdgcn_sched_barrier(0);
+                mma_row(IC<r & 1>{});
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            load_row(IC<0>{}, IC<0>{});
+            row(IC<0>{}); row(IC<1>{}); row(IC<2>{}); row(IC<3>{}); row(IC<4>{}); row(IC<5>{}); row(IC<6>{});
         }
+        tick(0);
         // ---- bias + ReLU -> staging (fp32, 16-byte chunk c of pixel p at chunk c ^ (p & 15): conflict-free writes and pool reads);
         // conv pixels outside the map are -inf, the max-pool's padding value
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const int p = (wave * 2 + b) * 16 + lr;
-            if (!dup[b]) {
+            if (!dup[b] && !(dbg & 4)) {
                 const int i = p / SP_CC, j = p - i * SP_CC;
                 const int cr = 2 * py0 - 1 + i, cc = 2 * px0 - 1 + j;
                 const bool ok = (unsigned)cr < (unsigned)CH && (unsigned)cc < (unsigned)CW;
@@ -159,12 +209,22 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const char* __restric
                 }
             }
         }
-        __syncthreads();
+        tick(1);
+        __syncthreads();   // A
+        tick(2);
+        put(0, pre0);
+        put(1, pre1);
+        put(2, pre2);
+        {   // the patch after next (the last tiles fetch the last tile again: no branch around the loads)
+            const int tn = min(t + 2 * G, total - 1);
+            pre0 = fetch1(tn, 0); pre1 = fetch1(tn, 1); pre2 = fetch1(tn, 2);
+        }
+        tick(3);
         // ---- 3 x 3 / 2 max-pool over the staging -> f16x2, 56 pixels x 16 chunks of 4 channels
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int item = tid + 512 * k;
-            if (item < SP_PH * SP_PW * 16) {
+            if (item < SP_PH * SP_PW * 16 && !(dbg & 1)) {
                 const int q = item >> 4, c = item & 15;
                 const int qy = q / SP_PW, qx = q - qy * SP_PW;
                 const int py = py0 + qy, px = px0 + qx;
@@ -183,8 +243,13 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const char* __restric
                 }
             }
         }
+        tick(4);
+        __syncthreads();   // B
+        tick(5);
     }
     f16x2_raise(range_mask);
+    if ((dbg & 8) && prof && lane == 0)
+        for (int k = 0; k < 6; ++k) atomicAdd(prof + k, (unsigned long long)tk[k]);
 }
 
 bool stem_pool_eligible(int dtype, int cout, int Kp, int KH, int H, int W) {
@@ -205,10 +270,26 @@ int k_stem_pool(int dtype, const void* xpad, const void* w, const float* bias, f
     OCRVI_TRY(device_cus(&n_cu));
     const int total = N * tyN * txN;
     const int grid = cdiv(total, cdiv(total, std::min(total, n_cu)));   // one persistent workgroup per CU, equal tile counts
+    static const int dbg = getenv("OCRVI_STEM_DBG") ? atoi(getenv("OCRVI_STEM_DBG")) : 0;
     OCRVI_TRY(ensure_max_smem((const void*)stem_pool_kernel, SP_SMEM));
+    unsigned long long* prof = nullptr;
+    if (dbg & 8) {   // development: phase cycles, printed per launch (synchronises)
+        static unsigned long long* dbuf = nullptr;
+        if (!dbuf) OCRVI_HIP(hipMalloc((void**)&dbuf, 64));
+        OCRVI_HIP(hipMemsetAsync(dbuf, 0, 64, s));
+        prof = dbuf;
+    }
     hipLaunchKernelGGL(stem_pool_kernel, dim3(grid), dim3(512), SP_SMEM, s, (const char*)xpad, (const char*)w, bias, wscale, (char*)y, N, CH, CW, OH,
-                       OW, Hp, Wp, tyN, txN);
+                       OW, Hp, Wp, tyN, txN, dbg, prof);
     OCRVI_HIP(hipGetLastError());
+    if (prof) {
+        unsigned long long h[6];
+        OCRVI_HIP(hipMemcpyAsync(h, prof, 48, hipMemcpyDeviceToHost, s));
+        OCRVI_HIP(hipStreamSynchronize(s));
+        const double wv = 8.0 * grid, tiles = (double)total / grid;
+        fprintf(stderr, "stem_pool grid %d tiles/wg %.1f: cycles per wave and tile: mfma %.0f staging %.0f barrier A %.0f patch write + fetch issue %.0f pool %.0f barrier B %.0f\n",
+                grid, tiles, h[0] / wv / tiles, h[1] / wv / tiles, h[2] / wv / tiles, h[3] / wv / tiles, h[4] / wv / tiles, h[5] / wv / tiles);
+    }
     return OCRVI_OK;
 }
 
