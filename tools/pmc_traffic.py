@@ -38,7 +38,7 @@ def tag_of(name):
     m = re.search(r"attention(16)?_kernel<(float|__bf16|_Float16|ocrvi::f16x2_t)", name)
     if m:
         return "attention_hd32_" + DEM[m.group(2)]
-    m = re.search(r"dcn_pipe_kernel<(float|__bf16|_Float16|ocrvi::f16x2_t), (\d+)>", name)
+    m = re.search(r"dcn_pipe_kernel<(float|__bf16|_Float16|ocrvi::f16x2_t), (\d+)(?:, (?:true|false))?>", name)
     if m:
         return f"dcn3x3_pipe128x{m.group(2)}_{DEM[m.group(1)]}"
     m = re.search(r"offs_conv_kernel<(float|__bf16|_Float16|ocrvi::f16x2_t)", name)
@@ -71,6 +71,8 @@ def tag_of(name):
     m = re.search(r"gconv32_kernelI(DF16b|DF16_)", name)
     if m:
         return "gconv3x3_128x32_" + DT[m.group(1)]
+    if "stem_pool_kernel" in name:
+        return "stem_pool_f16x2"
     m = re.search(r"ocrvi::?(\w+?)_kernel|5ocrvi\d+(\w+?)_kernel", name)
     return (m.group(1) or m.group(2)) if m else name[:60]
 
