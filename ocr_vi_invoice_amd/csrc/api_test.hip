@@ -268,7 +268,7 @@ extern "C" int ocrvi_test_mlp(int device, int dtype, float* x, const float* ln_g
                               const float* w2_host, const float* b2_host, const float* next_g_host, const float* next_b_host, int want_xn, int M, int D,
                               float* xn_out, int iters, float* avg_ms) {
     OCRVI_CHECK(x && ln_g_host && ln_b_host && w1_host && b1_host && w2_host && b2_host && M > 0, OCRVI_EINVAL, "test_mlp: bad argument");
-    OCRVI_CHECK(mlp_fused_eligible(dtype, D), OCRVI_EINVAL, "test_mlp: the fused MLP needs a 16-bit dtype and D in {128, 256, 384} (got dtype %d, D %d)", dtype, D);
+    OCRVI_CHECK(mlp_fused_eligible(dtype, D), OCRVI_EINVAL, "test_mlp: the fused MLP needs a 16-bit dtype and D in {128, 256, 384}, or f16x2 and D in {128, 256} (got dtype %d, D %d)", dtype, D);
     OCRVI_HIP(hipSetDevice(device));
     Scratch sc;
     OCRVI_TRY(sc.init());

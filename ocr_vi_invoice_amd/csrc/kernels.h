@@ -21,6 +21,11 @@ int k_layernorm(int dtype, const void* x, int x_f32, void* out, int out_f32, con
 // residual stream x [M][D]; when xn != null also writes xn [M][D] T = LN(x_new; next_g, next_b), or T(x_new) when next_g == null.
 // wstream = pack_mlp_stream(fc1.weight [4D][D], fc2.weight [D][4D]) uploaded to the device; b1 [4D], b2 [D] device fp32.
 bool mlp_fused_eligible(int dtype, int D);
+// f16x2, D = 128 / 256 (mlp_x2.hip): same contract; the stream carries its two weight scales behind the units
+bool mlp_x2_eligible(int dtype, int D);
+void pack_mlp_x2_stream(const float* w1, const float* w2, int D, std::vector<char>& out);
+int k_mlp_x2(float* x, void* xn, const float* ln_g, const float* ln_b, const float* next_g, const float* next_b, const void* wstream, const float* b1,
+             const float* b2, int M, int D, hipStream_t s);
 void pack_mlp_stream(const float* w1, const float* w2, int D, int dtype, std::vector<char>& out);
 int k_mlp_fused(int dtype, float* x, void* xn, const float* ln_g, const float* ln_b, const float* next_g, const float* next_b, const void* wstream,
                 const float* b1, const float* b2, int M, int D, hipStream_t s);

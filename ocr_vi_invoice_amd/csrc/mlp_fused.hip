@@ -336,6 +336,7 @@ __global__ __launch_bounds__(512 / TB, WPS) void mlp_fused_kernel(const MlpParam
 // elements of K), its fc2 slice NP W2 pieces (piece p2 = output rows 128 p2 .. + 128, each 64 elements = hidden chunk hc in the k-slot order
 // the accumulator lanes produce: position 16 g + 8 h + j  <->  hidden 16 (2 h + (j >> 2)) + 4 g + (j & 3)).
 void pack_mlp_stream(const float* w1, const float* w2, int D, int dtype, std::vector<char>& out) {
+    if (dtype == OCRVI_F16X2) return pack_mlp_x2_stream(w1, w2, D, out);
     const int H4 = 4 * D, NCH = H4 / 64, NP = D / 128;
     const size_t esz = dtype_size(dtype);
     std::vector<float> buf((size_t)NCH * 2 * NP * (kPiece / esz));
@@ -368,7 +369,10 @@ void pack_mlp_stream(const float* w1, const float* w2, int D, int dtype, std::ve
     convert_to_dtype(buf.data(), buf.size(), dtype, out.data());
 }
 
-bool mlp_fused_eligible(int dtype, int D) { return (dtype == OCRVI_BF16 || dtype == OCRVI_F16) && D % 128 == 0 && D >= 128 && D <= 384; }
+bool mlp_fused_eligible(int dtype, int D) {
+    if (dtype == OCRVI_F16X2) return mlp_x2_eligible(dtype, D);
+    return (dtype == OCRVI_BF16 || dtype == OCRVI_F16) && D % 128 == 0 && D >= 128 && D <= 384;
+}
 
 template <typename T, int D, int WPS, int R, int TB = 2>
 static int launch_mlp(const MlpParams& p, hipStream_t s) {
@@ -403,6 +407,7 @@ int k_mlp_fused(int dtype, float* x, void* xn, const float* ln_g, const float* l
                 const float* b1, const float* b2, int M, int D, hipStream_t s) {
     OCRVI_CHECK(mlp_fused_eligible(dtype, D) && x && ln_g && ln_b && wstream && b1 && b2 && M > 0 && M < (1 << 24), OCRVI_EINVAL,
                 "mlp_fused: bad argument (dtype %d, D %d, M %d)", dtype, D, M);
+    if (dtype == OCRVI_F16X2) return k_mlp_x2(x, xn, ln_g, ln_b, next_g, next_b, wstream, b1, b2, M, D, s);
     MlpParams p;
     p.x = x; p.xn = xn; p.ln_g = ln_g; p.ln_b = ln_b; p.next_g = next_g; p.next_b = next_b; p.wstream = wstream; p.b1 = b1; p.b2 = b2; p.M = M;
     char tag[64];
