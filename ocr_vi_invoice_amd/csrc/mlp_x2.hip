@@ -38,17 +38,24 @@ struct MlpX2Params {
     unsigned long long* prof = nullptr;   // development (OCRVI_MLPX2_PROF=1): cycles per wave in unit wait+barrier / GEMM1 (+ GELU) / GEMM2 / tile prologue + epilogue
 };
 
-template <int D, int R>
-__global__ __launch_bounds__(512, 2) void mlp_x2_kernel(const MlpX2Params p) {
+// TB = 16-token blocks per wave: 1 -> 8 waves of 16 tokens (two per SIMD, 256 registers each); 2 -> 4 waves of 32 tokens (one per SIMD with the
+// whole 512-entry file: the only way the normalised rows and the output accumulators of D = 384 fit -- 2 x 96 + 2 x 96 registers -- and every
+// weight fragment read from LDS feeds two token blocks).  SPLIT: the ring's unit is one HALF of a stream unit (the fc1 slice or the fc2 slice,
+// 128 D bytes; a wait + barrier before each GEMM) instead of the pair: a pair is 96 KB at D = 384, two of them do not fit the LDS.
+template <int D, int R, int TB, bool SPLIT>
+__global__ __launch_bounds__(512 / TB, TB == 2 ? 1 : 2) void mlp_x2_kernel(const MlpX2Params p) {
     typedef f16x2_t T;
     typedef Mma<T>::u4v U;
+    constexpr int NWV = 8 / TB, NT = 64 * NWV;   // waves, threads
     constexpr int KS = D / 32;         // 128-byte K-steps of GEMM1
     constexpr int NCH = 4 * D / 32;    // hidden chunks of 32
     constexpr int NB2 = D / 16;        // 16-channel output blocks of GEMM2
-    constexpr int W1B = 32 * D * 4;    // bytes of a unit's fc1 slice: [KS][32 hidden rows][128 B]
-    constexpr int UNIT = 256 * D;      // + fc2 slice [D output rows][128 B]
-    constexpr int IPW = UNIT / 1024 / 8;   // DMA instructions per wave per unit
-    constexpr int PF = R - 1;          // units in flight
+    constexpr int W1B = 32 * D * 4;    // bytes of a stream unit's fc1 slice: [KS][32 hidden rows][128 B]; the fc2 slice [D output rows][128 B] is as long
+    constexpr int UNIT = SPLIT ? W1B : 2 * W1B;   // the ring's unit
+    constexpr int IPW = UNIT / 1024 / NWV;        // DMA instructions per wave per ring unit
+    constexpr int PF = R - 1;          // ring units in flight
+    constexpr int NU = (NCH + 1) * (SPLIT ? 2 : 1);   // ring units per token tile
+    static_assert(UNIT % (1024 * NWV) == 0 && R >= 2, "ring geometry");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     float* const c_b1 = (float*)(smem + R * UNIT);     // [4D]
@@ -62,32 +69,32 @@ __global__ __launch_bounds__(512, 2) void mlp_x2_kernel(const MlpX2Params p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, g = lane >> 4;
     const bool next_ln = p.next_g != nullptr;
-    for (int i = tid; i < 4 * D; i += 512) c_b1[i] = p.b1[i];
-    for (int i = tid; i < D; i += 512) {
+    for (int i = tid; i < 4 * D; i += NT) c_b1[i] = p.b1[i];
+    for (int i = tid; i < D; i += NT) {
         c_b2[i] = p.b2[i];
         c_g[i] = p.ln_g[i];
         c_be[i] = p.ln_b[i];
         c_ng[i] = next_ln ? p.next_g[i] : 1.f;
         c_nb[i] = next_ln ? p.next_b[i] : 0.f;
     }
-    const float ws1 = ((const float*)(p.wstream + (size_t)(NCH + 1) * UNIT))[0], ws2 = ((const float*)(p.wstream + (size_t)(NCH + 1) * UNIT))[1];
+    const float* const tail = (const float*)(p.wstream + (size_t)(NCH + 1) * 2 * W1B);
+    const float ws1 = tail[0], ws2 = tail[1];
     __syncthreads();  // (also drains those loads: no VMEM op is in flight when the ring starts)
 
     const int ntiles = (p.M + 127) >> 7;
     const int G = gridDim.x;
     const int my_tiles = (ntiles - (int)blockIdx.x + G - 1) / G;
 
-    // ---- weight ring: unit q of the stream is unit q % NCH of the packed buffer, already in LDS image order; this wave copies 1-KiB pieces
-    // wave, wave + 8, ... of it.  Branch-free: past the end of the workgroup's stream it keeps fetching units nobody reads (their slots are
+    // ---- weight ring: ring unit q of the stream is unit q % NU of the packed buffer, already in LDS image order; this wave copies 1-KiB pieces
+    // wave, wave + NWV, ... of it.  Branch-free: past the end of the workgroup's stream it keeps fetching units nobody reads (their slots are
     // free), drained before the kernel ends.
     const char* const wbase = uniform_ptr(p.wstream);
     int prod_slot = 0, prod_mod = 0, cons_slot = 0;
-    constexpr int NU = NCH + 1;        // units per token tile: {fc1 slice of chunk k, fc2 slice of chunk k - 1}, k = 0 .. NCH (the missing halves are zeros)
     auto issue_unit = [&]() {
         const char* src = wbase + (size_t)prod_mod * UNIT + wave * 1024;
         const unsigned dst = lds0 + prod_slot * UNIT + wave * 1024;
 #pragma unroll
-        for (int j = 0; j < IPW; ++j) glds16(src + j * 8192, (unsigned)lane * 16u, __builtin_amdgcn_readfirstlane(dst + j * 8192));
+        for (int j = 0; j < IPW; ++j) glds16(src + j * (NWV * 1024), (unsigned)lane * 16u, __builtin_amdgcn_readfirstlane(dst + j * (NWV * 1024)));
         prod_slot = prod_slot + 1 == R ? 0 : prod_slot + 1;
         prod_mod = prod_mod + 1 == NU ? 0 : prod_mod + 1;
     };
@@ -114,13 +121,14 @@ __global__ __launch_bounds__(512, 2) void mlp_x2_kernel(const MlpX2Params p) {
 
     for (int t = 0; t < my_tiles; ++t) {
         const int tile = (int)blockIdx.x + t * G;
-        const int tok0 = tile * 128 + wave * 16;
-        // ---- prologue: LayerNorm(x) of this wave's 16 tokens -> B-operand fragments.  Lane (lr, g) owns channels 32 ks + 8 g .. + 8 of token
-        // tok0 + lr for every K-step ks: the lane's 8 k-slots.
-        U xH[KS], xL[KS];
-        {
+        const int tok0 = tile * 128 + wave * (16 * TB);
+        // ---- prologue: LayerNorm(x) of this wave's tokens -> B-operand fragments.  Lane (lr, g) of token block b owns channels 32 ks + 8 g .. + 8
+        // of token tok0 + 16 b + lr for every K-step ks: the lane's 8 k-slots.
+        U xH[KS][TB], xL[KS][TB];
+#pragma unroll
+        for (int b = 0; b < TB; ++b) {
             float xv[KS][8];
-            const int tok = min(tok0 + lr, p.M - 1);
+            const int tok = min(tok0 + 16 * b + lr, p.M - 1);
             const float* xr = p.x + (size_t)tok * D + 8 * g;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -156,35 +164,38 @@ __global__ __launch_bounds__(512, 2) void mlp_x2_kernel(const MlpX2Params p) {
                     o[4 * q + 3] = (xv[ks][4 * q + 3] - mean) * rstd * gv.w + bv.w;
                 }
                 const uint4 c0 = Chunk<T>::pack(o), c1 = Chunk<T>::pack(o + 4);
-                Mma<T>::regroup(c0, c1, xH[ks], xL[ks]);
+                Mma<T>::regroup(c0, c1, xH[ks][b], xL[ks][b]);
             }
         }
         // every VMEM op issued so far by this wave (ring DMAs, the previous tile's stores, the loads above) has completed: the counted
         // waits of the main loop start from the DMAs issued from here on (any older unit has landed)
         wait_vm_only<0>();
 
-        f32x4 acc2[NB2];
+        f32x4 acc2[NB2][TB];
 #pragma unroll
-        for (int a = 0; a < NB2; ++a) acc2[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < NB2; ++a)
+#pragma unroll
+            for (int b = 0; b < TB; ++b) acc2[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
         // Software pipeline over the chunks: unit k of the stream = {fc1 slice of chunk k, fc2 slice of chunk k - 1}; while the matrix pipe runs
-        // GEMM1(k), the wave's vector instructions do bias + GELU of chunk k - 1 (one or two values behind every K-step's MFMAs), then GEMM2(k - 1):
+        // GEMM1(k), the wave's vector instructions do bias + GELU of chunk k - 1 (a few values behind every K-step's MFMAs), then GEMM2(k - 1):
         //   G1(0);   for k = 1 .. NCH - 1: [G1(k) | gelu(k - 1)]; G2(k - 1);   gelu(NCH - 1); G2(NCH - 1)
-        f32x4 hacc[2], hprev[2];
-        float hv[8];
-        constexpr int VPK = 8 / KS;      // GELU values per K-step of GEMM1
-        static_assert(KS == 4 || KS == 8, "D = 128 or 256");
-        auto gelu_vals = [&](int i0, int n, const float4 (&bv)[2]) {   // values i0 .. i0 + n of the previous chunk: i = 4 a + r
+        f32x4 hacc[2][TB], hprev[2][TB];
+        constexpr int NV = 8 * TB;       // GELU values per chunk and lane: i = 8 b + 4 a + r, in place in hprev[a][b][r]
+        auto gelu_vals = [&](int i0, int i1, const float* bp) {   // bp = c_b1 + 32 c + 4 g (read where used: the biases are not kept in registers)
 #pragma unroll
-            for (int i = i0; i < i0 + n; ++i) {
-                const int a = i >> 2, r = i & 3;
-                const float bb = r == 0 ? bv[a].x : (r == 1 ? bv[a].y : (r == 2 ? bv[a].z : bv[a].w));
-                hv[i] = gelu_erf(hprev[a][r] * ws1 + bb);
+            for (int i = i0; i < i1; ++i) {
+                const int b = i >> 3, a = (i >> 2) & 1, r = i & 3;
+                hprev[a][b][r] = gelu_erf(hprev[a][b][r] * ws1 + bp[16 * a + r]);
             }
         };
-        auto g1 = [&](const char* U1, bool with_gelu, const float4 (&bv)[2]) {   // GEMM1 of this unit's chunk into hacc (+ the GELU of hprev)
-            hacc[0] = hacc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            uint4 wr[2][2][2];   // [set][hidden block][hi, lo], read one K-step ahead
+        auto g1 = [&](const char* U1, bool with_gelu, const float* bv) {   // GEMM1 of this unit's chunk into hacc (+ the GELU of hprev)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < TB; ++b) hacc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            constexpr int P1 = TB == 2 ? 1 : 2;   // K-steps read ahead (TB = 2: a fragment feeds twice the MFMAs, and the registers are needed elsewhere)
+            uint4 wr[P1 + 1][2][2];   // [set][hidden block][hi, lo]
             auto rd1 = [&](int ks, int set) {
 #pragma unroll
                 for (int a = 0; a < 2; ++a) {
@@ -193,81 +204,107 @@ __global__ __launch_bounds__(512, 2) void mlp_x2_kernel(const MlpX2Params p) {
                     wr[set][a][1] = *(const uint4*)(r + fo1);
                 }
             };
-            rd1(0, 0);
+#pragma unroll
+            for (int i = 0; i < P1; ++i) rd1(i, i);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                if (ks + 1 < KS) rd1(ks + 1, (ks + 1) & 1);
+                if (ks + P1 < KS) rd1(ks + P1, (ks + P1) % (P1 + 1));
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
-                    Mma<T>::three(Mma<T>::as_u4v(wr[ks & 1][a][0]), Mma<T>::as_u4v(wr[ks & 1][a][1]), xH[ks], xL[ks], hacc[a]);
-                if (with_gelu) gelu_vals(VPK * ks, VPK, bv);
+#pragma unroll
+                    for (int b = 0; b < TB; ++b)
+                        Mma<T>::three(Mma<T>::as_u4v(wr[ks % (P1 + 1)][a][0]), Mma<T>::as_u4v(wr[ks % (P1 + 1)][a][1]), xH[ks][b], xL[ks][b], hacc[a][b]);
+                if (with_gelu) gelu_vals(NV * ks / KS, NV * (ks + 1) / KS, bv);
             }
         };
-        auto g2 = [&](const char* U2) {   // hv (chunk k - 1, after its GELU) -> quartets -> GEMM2 into acc2, fragments one output block ahead
-            uint4 w2r[2][2];   // [set][hi, lo]
+        auto g2 = [&](const char* U2) {   // hprev (chunk k - 1, after its GELU) -> quartets -> GEMM2 into acc2
+            // fragments PFD output blocks ahead (a block is only 3 TB MFMAs, an LDS read under load takes several times that; the four sets take
+            // the registers GEMM1's fragment sets use in its own phase)
+            constexpr int PFD = TB == 2 ? 2 : 3;
+            uint4 w2r[PFD + 1][2];   // [set][hi, lo]
             auto rd2 = [&](int ab, int set) {
                 const char* r = U2 + (16 * ab + lr) * 128;
                 w2r[set][0] = *(const uint4*)(r + fo0);
                 w2r[set][1] = *(const uint4*)(r + fo1);
             };
-            rd2(0, 0);
-            range_mask |= f16x2_out_of_range(hv) | f16x2_out_of_range(hv + 4);
-            // k-slot j = 4 a + r of this lane <-> hidden 32 c + 16 a + 4 g + r
-            const uint4 c0 = Chunk<T>::pack(hv), c1 = Chunk<T>::pack(hv + 4);
-            U hH, hL;
-            Mma<T>::regroup(c0, c1, hH, hL);
+#pragma unroll
+            for (int i = 0; i < PFD; ++i) rd2(i, i);
+            U hH[TB], hL[TB];
+#pragma unroll
+            for (int b = 0; b < TB; ++b) {
+                // k-slot j = 4 a + r of this lane <-> hidden 32 c + 16 a + 4 g + r
+                const float h0[4] = {hprev[0][b][0], hprev[0][b][1], hprev[0][b][2], hprev[0][b][3]};
+                const float h1[4] = {hprev[1][b][0], hprev[1][b][1], hprev[1][b][2], hprev[1][b][3]};
+                range_mask |= f16x2_out_of_range(h0) | f16x2_out_of_range(h1);
+                const uint4 c0 = Chunk<T>::pack(h0), c1 = Chunk<T>::pack(h1);
+                Mma<T>::regroup(c0, c1, hH[b], hL[b]);
+            }
 #pragma unroll
             for (int ab = 0; ab < NB2; ++ab) {
-                if (ab + 1 < NB2) rd2(ab + 1, (ab + 1) & 1);
-                Mma<T>::three(Mma<T>::as_u4v(w2r[ab & 1][0]), Mma<T>::as_u4v(w2r[ab & 1][1]), hH, hL, acc2[ab]);
+                if (ab + PFD < NB2) rd2(ab + PFD, (ab + PFD) % (PFD + 1));
+#pragma unroll
+                for (int b = 0; b < TB; ++b)
+                    Mma<T>::three(Mma<T>::as_u4v(w2r[ab % (PFD + 1)][0]), Mma<T>::as_u4v(w2r[ab % (PFD + 1)][1]), hH[b], hL[b], acc2[ab][b]);
             }
         };
-        auto bias_of = [&](int c, float4 (&bv)[2]) {
-            bv[0] = *(const float4*)(c_b1 + 32 * c + 4 * g);
-            bv[1] = *(const float4*)(c_b1 + 32 * c + 16 + 4 * g);
+        auto keep = [&]() {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < TB; ++b) hprev[a][b] = hacc[a][b];
         };
-        float4 bv[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+        // the fc2 slice of a stream unit: behind its fc1 slice in the same ring unit, or (SPLIT) the next ring unit
+        auto second = [&](const char* U1) -> const char* {
+            if constexpr (SPLIT) {
+                const char* u = next_unit();
+                tick(0);
+                return u;
+            } else {
+                return U1 + W1B;
+            }
+        };
+        const float* const bias_g = c_b1 + 4 * g;
         tick(3);
         {
             const char* const U1 = next_unit();
             tick(0);
-            g1(U1, false, bv);
+            g1(U1, false, bias_g);
             tick(1);
+            (void)second(U1);    // (the fc2 half of stream unit 0 is zeros: nothing to multiply yet)
         }
-        hprev[0] = hacc[0]; hprev[1] = hacc[1];
+        keep();
         for (int k = 1; k < NCH; ++k) {
             const char* const U1 = next_unit();
             tick(0);
-            bias_of(k - 1, bv);
-            g1(U1, true, bv);
+            g1(U1, true, bias_g + 32 * (k - 1));
             tick(1);
-            g2(U1 + W1B);
+            g2(second(U1));
             tick(2);
-            hprev[0] = hacc[0]; hprev[1] = hacc[1];
+            keep();
         }
         {
-            const char* const U1 = next_unit();
+            const char* const U1 = next_unit();   // (its fc1 half is zeros)
             tick(0);
-            bias_of(NCH - 1, bv);
-            gelu_vals(0, 8, bv);
-            g2(U1 + W1B);
+            gelu_vals(0, NV, bias_g + 32 * (NCH - 1));
+            g2(second(U1));
             tick(2);
         }
 
-        // ---- epilogue: x <- x + fc2(..) + b2 (lane: channels 16 a + 4 g .. + 4 of token tok0 + lr), then the optional next norm / cast
-        {
-            const int tok = tok0 + lr;
+        // ---- epilogue: x <- x + fc2(..) + b2 (lane: channels 16 a + 4 g .. + 4 of token tok0 + 16 b + lr), then the optional next norm / cast
+#pragma unroll
+        for (int b = 0; b < TB; ++b) {
+            const int tok = tok0 + 16 * b + lr;
             const bool ok = tok < p.M;
             float* xr = p.x + (size_t)(ok ? tok : 0) * D + 4 * g;
             float sum = 0.f;
 #pragma unroll
             for (int a = 0; a < NB2; ++a) {
-                const float4 bv = *(const float4*)(c_b2 + 16 * a + 4 * g);
+                const float4 bv2 = *(const float4*)(c_b2 + 16 * a + 4 * g);
                 float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (ok) rv = *(const float4*)(xr + 16 * a);
-                f32x4 v = acc2[a];
-                v[0] = v[0] * ws2 + bv.x + rv.x; v[1] = v[1] * ws2 + bv.y + rv.y; v[2] = v[2] * ws2 + bv.z + rv.z; v[3] = v[3] * ws2 + bv.w + rv.w;
-                acc2[a] = v;
+                f32x4 v = acc2[a][b];
+                v[0] = v[0] * ws2 + bv2.x + rv.x; v[1] = v[1] * ws2 + bv2.y + rv.y; v[2] = v[2] * ws2 + bv2.z + rv.z; v[3] = v[3] * ws2 + bv2.w + rv.w;
+                acc2[a][b] = v;
                 if (ok) *(float4*)(xr + 16 * a) = make_float4(v[0], v[1], v[2], v[3]);
                 sum += v[0] + v[1] + v[2] + v[3];
             }
@@ -281,7 +318,7 @@ __global__ __launch_bounds__(512, 2) void mlp_x2_kernel(const MlpX2Params p) {
 #pragma unroll
                     for (int a = 0; a < NB2; ++a)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) { const float d = acc2[a][r] - mean; sq += d * d; }
+                        for (int r = 0; r < 4; ++r) { const float d = acc2[a][b][r] - mean; sq += d * d; }
                     sq += __shfl_xor(sq, 16);
                     sq += __shfl_xor(sq, 32);
                     rstd = rsqrtf(sq / (float)D + 1e-5f);
@@ -289,10 +326,10 @@ __global__ __launch_bounds__(512, 2) void mlp_x2_kernel(const MlpX2Params p) {
                 T* nr = (T*)p.xn + (size_t)(ok ? tok : 0) * D + 4 * g;
 #pragma unroll
                 for (int a = 0; a < NB2; ++a) {
-                    const float4 gv = *(const float4*)(c_ng + 16 * a + 4 * g), bv = *(const float4*)(c_nb + 16 * a + 4 * g);
-                    const f32x4 v = acc2[a];
-                    const float o[4] = {(v[0] - mean) * rstd * gv.x + bv.x, (v[1] - mean) * rstd * gv.y + bv.y, (v[2] - mean) * rstd * gv.z + bv.z,
-                                        (v[3] - mean) * rstd * gv.w + bv.w};
+                    const float4 gv = *(const float4*)(c_ng + 16 * a + 4 * g), bvn = *(const float4*)(c_nb + 16 * a + 4 * g);
+                    const f32x4 v = acc2[a][b];
+                    const float o[4] = {(v[0] - mean) * rstd * gv.x + bvn.x, (v[1] - mean) * rstd * gv.y + bvn.y, (v[2] - mean) * rstd * gv.z + bvn.z,
+                                        (v[3] - mean) * rstd * gv.w + bvn.w};
                     range_mask |= f16x2_out_of_range(o);
                     if (ok) *(uint4*)(nr + 16 * a) = Chunk<T>::pack(o);
                 }
@@ -309,7 +346,7 @@ __global__ __launch_bounds__(512, 2) void mlp_x2_kernel(const MlpX2Params p) {
 // ---------------------------------------------------------------- host: packing + launch
 bool mlp_x2_eligible(int dtype, int D) {
     static const bool off = getenv("OCRVI_MLP_X2") && atoi(getenv("OCRVI_MLP_X2")) == 0;
-    return !off && dtype == OCRVI_F16X2 && (D == 128 || D == 256);
+    return !off && dtype == OCRVI_F16X2 && (D == 128 || D == 256 || D == 384);
 }
 
 // power of two that puts the largest |w| into [2^13, 2^14) (finish_pack's rule, host_util.hip)
@@ -369,10 +406,10 @@ void pack_mlp_x2_stream(const float* w1, const float* w2, int D, std::vector<cha
     memcpy(out.data() + chunks.size(), tail, 8);
 }
 
-template <int D, int R>
+template <int D, int R, int TB, bool SPLIT>
 static int launch_mlp_x2(const MlpX2Params& p, hipStream_t s) {
-    const int smem = R * 256 * D + 9 * D * 4;
-    auto kern = mlp_x2_kernel<D, R>;
+    const int smem = R * (SPLIT ? 128 : 256) * D + 9 * D * 4;
+    auto kern = mlp_x2_kernel<D, R, TB, SPLIT>;
     OCRVI_TRY(ensure_max_smem((const void*)kern, smem));
     int n_cu = 0;
     OCRVI_TRY(device_cus(&n_cu));
@@ -386,31 +423,33 @@ static int launch_mlp_x2(const MlpX2Params& p, hipStream_t s) {
         OCRVI_HIP(hipMemsetAsync(dbuf, 0, 32, s));
         MlpX2Params q = p;
         q.prof = dbuf;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, s, q);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512 / TB), smem, s, q);
         unsigned long long h[4];
         OCRVI_HIP(hipMemcpyAsync(h, dbuf, 32, hipMemcpyDeviceToHost, s));
         OCRVI_HIP(hipStreamSynchronize(s));
-        const double wv = 8.0 * grid, units = (double)ntiles / grid * (4 * D / 32 + 1);
-        fprintf(stderr, "mlp_x2 D %d M %d grid %d: cycles per wave and unit: wait + barrier %.0f, GEMM1 (+ GELU) %.0f, GEMM2 %.0f; per tile prologue + epilogue %.0f\n", D, p.M, grid,
-                h[0] / wv / units, h[1] / wv / units, h[2] / wv / units, h[3] / wv / ((double)ntiles / grid));
+        const double wv = (8.0 / TB) * grid, units = (double)ntiles / grid * (4 * D / 32 + 1);
+        fprintf(stderr, "mlp_x2 D %d TB %d split %d M %d grid %d: cycles per wave and stream unit: wait + barrier %.0f, GEMM1 (+ GELU) %.0f, GEMM2 %.0f; per tile prologue + epilogue %.0f\n", D, TB,
+                (int)SPLIT, p.M, grid, h[0] / wv / units, h[1] / wv / units, h[2] / wv / units, h[3] / wv / ((double)ntiles / grid));
         return OCRVI_OK;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, s, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512 / TB), smem, s, p);
     OCRVI_HIP(hipGetLastError());
     return OCRVI_OK;
 }
 
 int k_mlp_x2(float* x, void* xn, const float* ln_g, const float* ln_b, const float* next_g, const float* next_b, const void* wstream, const float* b1,
              const float* b2, int M, int D, hipStream_t s) {
-    OCRVI_CHECK((D == 128 || D == 256) && x && ln_g && ln_b && wstream && b1 && b2 && M > 0 && M < (1 << 24), OCRVI_EINVAL,
+    OCRVI_CHECK((D == 128 || D == 256 || D == 384) && x && ln_g && ln_b && wstream && b1 && b2 && M > 0 && M < (1 << 24), OCRVI_EINVAL,
                 "mlp_x2: bad argument (D %d, M %d)", D, M);
     MlpX2Params p;
     p.x = x; p.xn = xn; p.ln_g = ln_g; p.ln_b = ln_b; p.next_g = next_g; p.next_b = next_b; p.wstream = (const char*)wstream; p.b1 = b1; p.b2 = b2; p.M = M;
     char tag[64];
     snprintf(tag, sizeof(tag), "mlp_fused_d%d_f16x2", D);
     ProfScope ps(tag, 2.0 * M * 8.0 * D * D, (double)M * D * (8.0 + (xn ? 4.0 : 0.0)) + 8.0 * D * D * 4.0, s);
-    if (D == 128) return launch_mlp_x2<128, 4>(p, s);
-    return launch_mlp_x2<256, 2>(p, s);
+    static const int tb2 = getenv("OCRVI_MLPX2_TB2") ? atoi(getenv("OCRVI_MLPX2_TB2")) : 0;   // (A/B: the 4-wave layout at D <= 256 too)
+    if (D == 128) return tb2 ? launch_mlp_x2<128, 8, 2, true>(p, s) : launch_mlp_x2<128, 4, 1, false>(p, s);
+    if (D == 256) return tb2 ? launch_mlp_x2<256, 4, 2, true>(p, s) : launch_mlp_x2<256, 2, 1, false>(p, s);
+    return launch_mlp_x2<384, 3, 2, true>(p, s);
 }
 
 }  // namespace ocrvi

@@ -49,3 +49,16 @@ def test_duo_gemm_isa_keeps_its_protocol():
         assert r["mfma"] > 0 and r["scratch"] == 0, (name, r["scratch"])
         assert len(r["compiler_vmcnt_waits"]) <= 1, (name, r["compiler_vmcnt_waits"])
         assert not r["m0_uses"], (name, r["m0_uses"][:3])
+
+
+@pytest.mark.skipif(not shutil.which("/opt/rocm/bin/hipcc"), reason="hipcc not available")
+def test_mlp_x2_isa_keeps_its_ring_protocol():
+    """mlp_x2.hip counts the vmcnt of its weight ring by hand: no scratch instruction inside the chunk loop of any build, none at all in the
+    8-wave builds (D = 128 / 256); the 4-wave D = 384 build fills all 512 registers and may spill loop-invariant values outside the loop."""
+    import check_ring_isa
+    rep = check_ring_isa.check_mlp_x2()
+    assert len(rep) >= 3
+    for name, (inner, outer, mfma) in rep.items():
+        assert mfma > 0 and inner == 0, (name, inner)
+        if "ILi384E" not in name:
+            assert outer == 0, (name, outer)

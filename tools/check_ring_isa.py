@@ -61,7 +61,7 @@ def touches_before_wait(body, start, dst):
     return hits
 
 
-ALL_SOURCES = ["conv_bf16.hip", "conv_f16.hip", "conv_f32.hip", "conv_f16x2.hip", "duo_f16x2.hip", "mlp_fused.hip", "attention.hip", "stem_pool.hip"]
+ALL_SOURCES = ["conv_bf16.hip", "conv_f16.hip", "conv_f32.hip", "conv_f16x2.hip", "duo_f16x2.hip", "mlp_fused.hip", "attention.hip", "stem_pool.hip", "mlp_x2.hip"]
 _ASM = {}
 
 
@@ -129,6 +129,35 @@ def check_duo(src="duo_f16x2.hip"):
         rep[name] = dict(scratch=sum("scratch_" in t for t, _ in body), mfma=sum("v_mfma" in t for t, _ in body),
                          compiler_vmcnt_waits=[t for i, (t, a) in enumerate(body) if not a and i < last_asm and t.startswith("s_waitcnt") and "vmcnt" in t],
                          m0_uses=[t for t, a in body if not a and re.search(r"\bm0\b", t)])
+    return rep
+
+
+def check_mlp_x2(src="mlp_x2.hip"):
+    """The f16x2 fused MLP (mlp_x2.hip) counts the vmcnt of its weight ring by hand.  name -> (scratch instructions inside the chunk loop -- loop
+    depth >= 2, where a spill would sit between the counted waits --, scratch instructions elsewhere, MFMA instructions).  The 4-wave D = 384
+    build uses all 512 registers and spills a few loop-invariant values OUTSIDE the chunk loop (tile prologue / epilogue: extra VMEM operations
+    there only make the next counted wait stricter); the 8-wave builds must not spill at all."""
+    lines = asm_of(src).split("\n")
+    rep = {}
+    for i, l in enumerate(lines):
+        m = re.match(r"(_ZN5ocrvi13mlp_x2_kernel\w*):", l)
+        if not m:
+            continue
+        depth, inner, outer, mfma = 0, 0, 0, 0
+        for t in lines[i + 1:]:
+            if t.strip().startswith(".Lfunc_end"):
+                break
+            if re.match(r"\s*(\.LBB\w+:|; %bb\.\d+:)", t):
+                d = re.search(r"Depth=(\d+)", t)
+                depth = int(d.group(1)) if d else 0
+            body = t.split(";")[0]
+            if "scratch_" in body:
+                if depth >= 2:
+                    inner += 1
+                else:
+                    outer += 1
+            mfma += "v_mfma" in body
+        rep[m.group(1)] = (inner, outer, mfma)
     return rep
 
 
