@@ -140,15 +140,19 @@ template <> struct Chunk<f16x2_t> {   // [4 hi | 4 lo]: u.x = (hi0, hi1), u.y = 
         f[2] = fma_mix_lo(1.0f, u.w, (float)r.h[2]);
         f[3] = fma_mix_hi(1.0f, u.w, (float)r.h[3]);
     }
+    // (the conversions as two-element vector converts: hipcc then emits v_cvt_pk_f16_f32 -- one instruction per PAIR, round to nearest even;
+    // written element by element it emitted v_cvt_f16_f32 + v_cvt_f16_f32_sdwa + v_or per pair: 16 vector instructions per chunk instead of 8,
+    // in epilogues that issue in the shadow of the partner wave's MFMAs)
     __device__ static inline uint4 pack(const float* f) {
-        union { f16_t h[4]; uint2 u; } hi, lo;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) hi.h[i] = (f16_t)f[i];                       // v_cvt_pk_f16_f32, round to nearest even
-        lo.h[0] = (f16_t)fma_mix_lo(-1.0f, hi.u.x, f[0]);                        // x - hi is exact in fp32
-        lo.h[1] = (f16_t)fma_mix_hi(-1.0f, hi.u.x, f[1]);
-        lo.h[2] = (f16_t)fma_mix_lo(-1.0f, hi.u.y, f[2]);
-        lo.h[3] = (f16_t)fma_mix_hi(-1.0f, hi.u.y, f[3]);
-        return make_uint4(hi.u.x, hi.u.y, lo.u.x, lo.u.y);
+        typedef float f2v __attribute__((ext_vector_type(2)));
+        typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+        const unsigned h0 = __builtin_bit_cast(unsigned, __builtin_convertvector((f2v){f[0], f[1]}, h2v));
+        const unsigned h1 = __builtin_bit_cast(unsigned, __builtin_convertvector((f2v){f[2], f[3]}, h2v));
+        const float l0 = fma_mix_lo(-1.0f, h0, f[0]), l1 = fma_mix_hi(-1.0f, h0, f[1]);    // x - hi is exact in fp32
+        const float l2 = fma_mix_lo(-1.0f, h1, f[2]), l3 = fma_mix_hi(-1.0f, h1, f[3]);
+        const unsigned q0 = __builtin_bit_cast(unsigned, __builtin_convertvector((f2v){l0, l1}, h2v));
+        const unsigned q1 = __builtin_bit_cast(unsigned, __builtin_convertvector((f2v){l2, l3}, h2v));
+        return make_uint4(h0, h1, q0, q1);
     }
 };
 

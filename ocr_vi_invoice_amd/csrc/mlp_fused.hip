@@ -289,11 +289,16 @@ __global__ __launch_bounds__(512 / TB, WPS) void mlp_fused_kernel(const MlpParam
             const bool ok = tok < p.M;
             float* xr = p.x + (size_t)(ok ? tok : 0) * D + 4 * g;
             float sum = 0.f;
+            // (all residual loads first: x is read and written through the same pointer, so inside one loop every load would wait behind the
+            // previous block's store -- NB2 serial round trips to memory)
+            float4 rvs[NB2];
+#pragma unroll
+            for (int a = 0; a < NB2; ++a) rvs[a] = *(const float4*)(xr + 16 * a);   // (unconditional: a token past M reads row 0 and stores nothing --
+                                                                                    // under `if (ok)` every load got its own branch and its own vmcnt(0))
 #pragma unroll
             for (int a = 0; a < NB2; ++a) {
                 const float4 bv = *(const float4*)(c_b2 + 16 * a + 4 * g);
-                float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok) rv = *(const float4*)(xr + 16 * a);
+                const float4 rv = rvs[a];
                 f32x4 v = acc2[a][b];
                 v[0] += bv.x + rv.x; v[1] += bv.y + rv.y; v[2] += bv.z + rv.z; v[3] += bv.w + rv.w;
                 acc2[a][b] = v;

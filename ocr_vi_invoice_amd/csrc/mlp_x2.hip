@@ -35,7 +35,9 @@ struct MlpX2Params {
     const float* b1 = nullptr;     // [4D]
     const float* b2 = nullptr;     // [D]
     int M = 0;
-    unsigned long long* prof = nullptr;   // development (OCRVI_MLPX2_PROF=1): cycles per wave in unit wait+barrier / GEMM1 (+ GELU) / GEMM2 / tile prologue + epilogue
+    int stagger = 0;               // shader cycles between the start phases of the workgroups (see the kernel)
+    int dbg = 0;                   // OCRVI_MLPX2_DBG (development, wrong results): 1 no x stores, 2 no xn stores, 4 no residual loads
+    unsigned long long* prof = nullptr;   // development (OCRVI_MLPX2_PROF=1): cycles per wave in unit wait+barrier / GEMM1 (+ GELU) / GEMM2 / tile epilogue / prologue / drain
 };
 
 // TB = 16-token blocks per wave: 1 -> 8 waves of 16 tokens (two per SIMD, 256 registers each); 2 -> 4 waves of 32 tokens (one per SIMD with the
@@ -106,8 +108,15 @@ __global__ __launch_bounds__(512 / TB, TB == 2 ? 1 : 2) void mlp_x2_kernel(const
         return s;
     };
     for (int i = 0; i < PF; ++i) issue_unit();
+    // Every workgroup's tile takes the same time, so left alone all CUs reach their tile epilogue (read x, write x and xn: 512 KB per CU at
+    // D = 256) in the same few microseconds and the chip's HBM serves one burst per tile while it idles during the chunk loops: the epilogue took
+    // 50 k of a tile's 260 k cycles.  Four start phases, `stagger` cycles apart, spread the bursts (the last phase ends 3 x stagger late, once).
+    if (p.stagger > 0) {
+        const long long until = clock64() + (long long)(blockIdx.x & 3) * p.stagger;
+        while (clock64() < until) __builtin_amdgcn_s_sleep(64);
+    }
 
-    long long tk[4] = {0, 0, 0, 0}, tk0 = p.prof ? clock64() : 0;
+    long long tk[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, tk0 = p.prof ? clock64() : 0;
     auto tick = [&](int k) {
         if (p.prof) {
             const long long c = clock64();
@@ -167,9 +176,11 @@ __global__ __launch_bounds__(512 / TB, TB == 2 ? 1 : 2) void mlp_x2_kernel(const
                 Mma<T>::regroup(c0, c1, xH[ks][b], xL[ks][b]);
             }
         }
+        tick(4);
         // every VMEM op issued so far by this wave (ring DMAs, the previous tile's stores, the loads above) has completed: the counted
         // waits of the main loop start from the DMAs issued from here on (any older unit has landed)
         wait_vm_only<0>();
+        tick(5);
 
         f32x4 acc2[NB2][TB];
 #pragma unroll
@@ -264,7 +275,6 @@ __global__ __launch_bounds__(512 / TB, TB == 2 ? 1 : 2) void mlp_x2_kernel(const
             }
         };
         const float* const bias_g = c_b1 + 4 * g;
-        tick(3);
         {
             const char* const U1 = next_unit();
             tick(0);
@@ -290,57 +300,75 @@ __global__ __launch_bounds__(512 / TB, TB == 2 ? 1 : 2) void mlp_x2_kernel(const
             tick(2);
         }
 
-        // ---- epilogue: x <- x + fc2(..) + b2 (lane: channels 16 a + 4 g .. + 4 of token tok0 + 16 b + lr), then the optional next norm / cast
+        // ---- epilogue: x <- x + fc2(..) + b2, then the optional next norm / cast.  The MFMA leaves lane 16 g + lr with channels 16 a + 4 g .. + 4 of
+        // token lr: four consecutive lanes then hold four DIFFERENT tokens, and a 16-byte access per lane touches four cache lines per lane quad
+        // (the memory pipe works quad by quad: 4 x the requests for the same bytes; the residual loads, the x stores and the xn stores took 60 k of a
+        // tile's 260 k cycles at D = 256).  One ds_bpermute per accumulator dword moves the values to lane 4 lr + g first: a quad is then one token's
+        // 64 contiguous bytes, and everything after it (bias, residual, statistics over a quad, xn) happens in that layout.
+        const int pn_tok = lane >> 2, pn_g = lane & 3;                      // this lane after the permutation: token pn_tok, channels 16 a + 4 pn_g .. + 4
+        const int pn_src = 4 * (16 * pn_g + pn_tok);                        // ds_bpermute byte address of the lane that holds them now
 #pragma unroll
         for (int b = 0; b < TB; ++b) {
-            const int tok = tok0 + 16 * b + lr;
+#pragma unroll
+            for (int a = 0; a < NB2; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc2[a][b][r] = __int_as_float(__builtin_amdgcn_ds_bpermute(pn_src, __float_as_int(acc2[a][b][r])));
+            const int tok = tok0 + 16 * b + pn_tok;
             const bool ok = tok < p.M;
-            float* xr = p.x + (size_t)(ok ? tok : 0) * D + 4 * g;
+            float* xr = p.x + (size_t)(ok ? tok : 0) * D + 4 * pn_g;
             float sum = 0.f;
+            // (all residual loads first and unconditional -- a token past M reads row 0 and stores nothing: under `if (ok)` every load got its own
+            // branch and its own vmcnt(0), and x is read and written through the same pointer)
+            float4 rvs[NB2];
+#pragma unroll
+            for (int a = 0; a < NB2; ++a) rvs[a] = (p.dbg & 4) ? make_float4(0.f, 0.f, 0.f, 0.f) : *(const float4*)(xr + 16 * a);
+            if (p.prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tick(6); }
 #pragma unroll
             for (int a = 0; a < NB2; ++a) {
-                const float4 bv2 = *(const float4*)(c_b2 + 16 * a + 4 * g);
-                float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok) rv = *(const float4*)(xr + 16 * a);
+                const float4 bv2 = *(const float4*)(c_b2 + 16 * a + 4 * pn_g);
+                const float4 rv = rvs[a];
                 f32x4 v = acc2[a][b];
                 v[0] = v[0] * ws2 + bv2.x + rv.x; v[1] = v[1] * ws2 + bv2.y + rv.y; v[2] = v[2] * ws2 + bv2.z + rv.z; v[3] = v[3] * ws2 + bv2.w + rv.w;
                 acc2[a][b] = v;
-                if (ok) *(float4*)(xr + 16 * a) = make_float4(v[0], v[1], v[2], v[3]);
+                if (ok && !(p.dbg & 1)) *(float4*)(xr + 16 * a) = make_float4(v[0], v[1], v[2], v[3]);
                 sum += v[0] + v[1] + v[2] + v[3];
             }
+            tick(7);
             if (p.xn) {
                 float mean = 0.f, rstd = 1.f;
-                if (next_ln) {
-                    sum += __shfl_xor(sum, 16);
-                    sum += __shfl_xor(sum, 32);
+                if (next_ln) {      // a token's D values sit in the four lanes of a quad
+                    sum += __shfl_xor(sum, 1);
+                    sum += __shfl_xor(sum, 2);
                     mean = sum / (float)D;
                     float sq = 0.f;
 #pragma unroll
                     for (int a = 0; a < NB2; ++a)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { const float d = acc2[a][b][r] - mean; sq += d * d; }
-                    sq += __shfl_xor(sq, 16);
-                    sq += __shfl_xor(sq, 32);
+                    sq += __shfl_xor(sq, 1);
+                    sq += __shfl_xor(sq, 2);
                     rstd = rsqrtf(sq / (float)D + 1e-5f);
                 }
-                T* nr = (T*)p.xn + (size_t)(ok ? tok : 0) * D + 4 * g;
+                tick(8);
+                T* nr = (T*)p.xn + (size_t)(ok ? tok : 0) * D + 4 * pn_g;
 #pragma unroll
                 for (int a = 0; a < NB2; ++a) {
-                    const float4 gv = *(const float4*)(c_ng + 16 * a + 4 * g), bvn = *(const float4*)(c_nb + 16 * a + 4 * g);
+                    const float4 gv = *(const float4*)(c_ng + 16 * a + 4 * pn_g), bvn = *(const float4*)(c_nb + 16 * a + 4 * pn_g);
                     const f32x4 v = acc2[a][b];
                     const float o[4] = {(v[0] - mean) * rstd * gv.x + bvn.x, (v[1] - mean) * rstd * gv.y + bvn.y, (v[2] - mean) * rstd * gv.z + bvn.z,
                                         (v[3] - mean) * rstd * gv.w + bvn.w};
                     range_mask |= f16x2_out_of_range(o);
-                    if (ok) *(uint4*)(nr + 16 * a) = Chunk<T>::pack(o);
+                    if (ok && !(p.dbg & 2)) *(uint4*)(nr + 16 * a) = Chunk<T>::pack(o);
                 }
             }
         }
+        tick(3);
     }
     wait_vm_only<0>();  // the ring's run-ahead fetches
     f16x2_raise(range_mask);
-    tick(3);
     if (p.prof && lane == 0)
-        for (int k = 0; k < 4; ++k) atomicAdd(p.prof + k, (unsigned long long)tk[k]);
+        for (int k = 0; k < 9; ++k) atomicAdd(p.prof + k, (unsigned long long)tk[k]);
 }
 
 // ---------------------------------------------------------------- host: packing + launch
@@ -416,23 +444,30 @@ static int launch_mlp_x2(const MlpX2Params& p, hipStream_t s) {
     const int ntiles = (p.M + 127) / 128;
     int grid = std::min(ntiles, n_cu);
     grid = cdiv(ntiles, cdiv(ntiles, grid));  // equal tile counts
+    static const int stagger_env = getenv("OCRVI_MLPX2_STAGGER") ? atoi(getenv("OCRVI_MLPX2_STAGGER")) : -1;
+    MlpX2Params ps = p;
+    ps.stagger = stagger_env >= 0 ? stagger_env : (D == 128 ? 12000 : (D == 256 ? 24000 : 40000));
+    if (ntiles < 2 * grid) ps.stagger = 0;   // (one tile per workgroup: nothing to spread)
+    static const int dbg_env = getenv("OCRVI_MLPX2_DBG") ? atoi(getenv("OCRVI_MLPX2_DBG")) : 0;
+    ps.dbg = dbg_env;
     static const bool prof = getenv("OCRVI_MLPX2_PROF") && atoi(getenv("OCRVI_MLPX2_PROF"));
     if (prof) {   // development: phase cycles, printed per launch (synchronises)
         static unsigned long long* dbuf = nullptr;
-        if (!dbuf) OCRVI_HIP(hipMalloc((void**)&dbuf, 32));
-        OCRVI_HIP(hipMemsetAsync(dbuf, 0, 32, s));
-        MlpX2Params q = p;
+        if (!dbuf) OCRVI_HIP(hipMalloc((void**)&dbuf, 72));
+        OCRVI_HIP(hipMemsetAsync(dbuf, 0, 72, s));
+        MlpX2Params q = ps;
         q.prof = dbuf;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512 / TB), smem, s, q);
-        unsigned long long h[4];
-        OCRVI_HIP(hipMemcpyAsync(h, dbuf, 32, hipMemcpyDeviceToHost, s));
+        unsigned long long h[9];
+        OCRVI_HIP(hipMemcpyAsync(h, dbuf, 72, hipMemcpyDeviceToHost, s));
         OCRVI_HIP(hipStreamSynchronize(s));
         const double wv = (8.0 / TB) * grid, units = (double)ntiles / grid * (4 * D / 32 + 1);
-        fprintf(stderr, "mlp_x2 D %d TB %d split %d M %d grid %d: cycles per wave and stream unit: wait + barrier %.0f, GEMM1 (+ GELU) %.0f, GEMM2 %.0f; per tile prologue + epilogue %.0f\n", D, TB,
-                (int)SPLIT, p.M, grid, h[0] / wv / units, h[1] / wv / units, h[2] / wv / units, h[3] / wv / ((double)ntiles / grid));
+        fprintf(stderr, "mlp_x2 D %d TB %d split %d M %d grid %d: cycles per wave and stream unit: wait + barrier %.0f, GEMM1 (+ GELU) %.0f, GEMM2 %.0f; per tile: epilogue (x loads %.0f, x update + stores %.0f, statistics %.0f, xn %.0f), prologue (loads + LayerNorm) %.0f, drain %.0f\n", D, TB,
+                (int)SPLIT, p.M, grid, h[0] / wv / units, h[1] / wv / units, h[2] / wv / units, h[6] / wv / ((double)ntiles / grid), h[7] / wv / ((double)ntiles / grid), h[8] / wv / ((double)ntiles / grid), h[3] / wv / ((double)ntiles / grid),
+                h[4] / wv / ((double)ntiles / grid), h[5] / wv / ((double)ntiles / grid));
         return OCRVI_OK;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512 / TB), smem, s, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512 / TB), smem, s, ps);
     OCRVI_HIP(hipGetLastError());
     return OCRVI_OK;
 }
