@@ -108,9 +108,9 @@ __global__ __launch_bounds__(512 / TB, TB == 2 ? 1 : 2) void mlp_x2_kernel(const
         return s;
     };
     for (int i = 0; i < PF; ++i) issue_unit();
-    // Every workgroup's tile takes the same time, so left alone all CUs reach their tile epilogue (read x, write x and xn: 512 KB per CU at
-    // D = 256) in the same few microseconds and the chip's HBM serves one burst per tile while it idles during the chunk loops: the epilogue took
-    // 50 k of a tile's 260 k cycles.  Four start phases, `stagger` cycles apart, spread the bursts (the last phase ends 3 x stagger late, once).
+    // (Experiment, OCRVI_MLPX2_STAGGER=cycles, off by default: four start phases `stagger` cycles apart, to test whether the tile epilogues of all
+    // CUs -- which fall into the same few microseconds -- starve each other of HBM bandwidth.  They do not: 12 k ... 60 k cycles of stagger only add
+    // their own delay; removing every load and store of the epilogue saves 7 %.  The epilogue's cost is its ~1 300 vector instructions.)
     if (p.stagger > 0) {
         const long long until = clock64() + (long long)(blockIdx.x & 3) * p.stagger;
         while (clock64() < until) __builtin_amdgcn_s_sleep(64);
@@ -446,8 +446,7 @@ static int launch_mlp_x2(const MlpX2Params& p, hipStream_t s) {
     grid = cdiv(ntiles, cdiv(ntiles, grid));  // equal tile counts
     static const int stagger_env = getenv("OCRVI_MLPX2_STAGGER") ? atoi(getenv("OCRVI_MLPX2_STAGGER")) : -1;
     MlpX2Params ps = p;
-    ps.stagger = stagger_env >= 0 ? stagger_env : (D == 128 ? 12000 : (D == 256 ? 24000 : 40000));
-    if (ntiles < 2 * grid) ps.stagger = 0;   // (one tile per workgroup: nothing to spread)
+    ps.stagger = stagger_env > 0 ? stagger_env : 0;   // (experiment, off: see the kernel)
     static const int dbg_env = getenv("OCRVI_MLPX2_DBG") ? atoi(getenv("OCRVI_MLPX2_DBG")) : 0;
     ps.dbg = dbg_env;
     static const bool prof = getenv("OCRVI_MLPX2_PROF") && atoi(getenv("OCRVI_MLPX2_PROF"));
