@@ -73,6 +73,9 @@ def tag_of(name):
         return "gconv3x3_128x32_" + DT[m.group(1)]
     if "stem_pool_kernel" in name:
         return "stem_pool_f16x2"
+    m = re.search(r"mlp_x2_kernel<(\d+)|mlp_x2_kernelILi(\d+)E", name)
+    if m:
+        return f"mlp_fused_d{m.group(1) or m.group(2)}_f16x2"
     m = re.search(r"ocrvi::?(\w+?)_kernel|5ocrvi\d+(\w+?)_kernel", name)
     return (m.group(1) or m.group(2)) if m else name[:60]
 
