@@ -467,21 +467,29 @@ __global__ __launch_bounds__(256, (ConvOccT<T, AMODE, BM, BN>::value)) void conv
             // f16x2, 128-wide tiles (two workgroups per CU: registers to spare): both chunks at once, regrouped into (hi, lo) quartets, three
             // MFMAs per fragment pair.  The narrower tiles live on occupancy (4-5 workgroups per CU) and keep the two-chunk loop below
             // (four MFMAs per pair): holding both chunks cost them a workgroup per CU and 8-13 % (measured).
-            if constexpr (IsSplit<T>::value && BN >= 128) {
+#ifdef OCRVI_X2_THREE_ALL      // (experiment: the three-product form on the narrow tiles too, regrouped in place)
+            constexpr bool kThree = IsSplit<T>::value;
+#else
+            constexpr bool kThree = IsSplit<T>::value && BN >= 128;
+#endif
+            if constexpr (kThree) {
                 typedef typename Mma<T>::u4v U;
-                U xH[MI], xL[MI];
+                uint4 xr[MI][2];   // regrouped IN PLACE (two v_swap_b32 per fragment pair: no copies, no second register set)
 #pragma unroll
                 for (int b = 0; b < MI; ++b) {
                     const char* r = As + (wm * TM + b * 16 + lr) * 128;
-                    Mma<T>::regroup(*(const uint4*)(r + fo0), *(const uint4*)(r + fo1), xH[b], xL[b]);
+                    xr[b][0] = *(const uint4*)(r + fo0);
+                    xr[b][1] = *(const uint4*)(r + fo1);
+                    Mma<T>::regroup_swap(xr[b][0], xr[b][1]);
                 }
 #pragma unroll
                 for (int a = 0; a < NI; ++a) {
                     const char* r = Bs + (wn * TN + a * 16 + lr) * 128;
-                    U wH, wL;
-                    Mma<T>::regroup(*(const uint4*)(r + fo0), *(const uint4*)(r + fo1), wH, wL);
+                    uint4 w0 = *(const uint4*)(r + fo0), w1 = *(const uint4*)(r + fo1);
+                    Mma<T>::regroup_swap(w0, w1);
 #pragma unroll
-                    for (int b = 0; b < MI; ++b) Mma<T>::three(wH, wL, xH[b], xL[b], acc[a][b]);
+                    for (int b = 0; b < MI; ++b)
+                        Mma<T>::three(Mma<T>::as_u4v(w0), Mma<T>::as_u4v(w1), Mma<T>::as_u4v(xr[b][0]), Mma<T>::as_u4v(xr[b][1]), acc[a][b]);
                 }
             } else
 #pragma unroll
