@@ -467,12 +467,9 @@ __global__ __launch_bounds__(256, (ConvOccT<T, AMODE, BM, BN>::value)) void conv
             // f16x2, 128-wide tiles (two workgroups per CU: registers to spare): both chunks at once, regrouped into (hi, lo) quartets, three
             // MFMAs per fragment pair.  The narrower tiles live on occupancy (4-5 workgroups per CU) and keep the two-chunk loop below
             // (four MFMAs per pair): holding both chunks cost them a workgroup per CU and 8-13 % (measured).
-#ifdef OCRVI_X2_THREE_ALL      // (experiment: the three-product form on the narrow tiles too, regrouped in place)
-            constexpr bool kThree = IsSplit<T>::value;
-#else
-            constexpr bool kThree = IsSplit<T>::value && BN >= 128;
-#endif
-            if constexpr (kThree) {
+            // (round 4: with the in-place regrouping the narrow tiles keep their occupancy in the three-product form too, but gain only 2-5 %
+            // -- they are not bound by the matrix pipe -- so they stay as they are)
+            if constexpr (IsSplit<T>::value && BN >= 128) {
                 typedef typename Mma<T>::u4v U;
                 uint4 xr[MI][2];   // regrouped IN PLACE (two v_swap_b32 per fragment pair: no copies, no second register set)
 #pragma unroll
