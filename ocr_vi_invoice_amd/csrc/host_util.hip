@@ -273,9 +273,13 @@ bool gemm_ring_eligible(const ConvParams& p, int amode, int dtype) {
 // why (a wave alone on its SIMD drives the matrix pipe at about half the rate two waves reach together, so the "solo" MFMA steps beside
 // the other group's epilogue are no shorter than shared ones) is measured in profiles/r04_duo.md with tools/mfma_mix.hip.
 bool gemm_duo_eligible(const ConvParams& p, int amode, int dtype) {
-    static const bool on = getenv("OCRVI_GEMM_DUO") && atoi(getenv("OCRVI_GEMM_DUO")) != 0;
-    if (!on || dtype != OCRVI_F16X2 || amode != AM_CONV1) return false;
+    // OCRVI_GEMM_DUO: unset / 0 never; 1 every shape the kernel takes (ties gemm_ring end to end: profiles/r04_duo.md); 2 only wide outputs on a
+    // short K with a plain epilogue -- the recogniser's qkv projections (N = 3 D >= 768, K = D <= 384): 17.6 against 18.6 ms per step there,
+    // nothing measurable end to end (293-297 invoices/s either way).  The kernels are bit-identical, so the choice is invisible in the results.
+    static const int mode = getenv("OCRVI_GEMM_DUO") ? atoi(getenv("OCRVI_GEMM_DUO")) : 0;
+    if (mode == 0 || dtype != OCRVI_F16X2 || amode != AM_CONV1) return false;
     if (!gemm_ring_eligible(p, amode, dtype)) return false;
+    if (mode == 2 && !(p.Np >= 768 && p.Kp <= 384 && p.act == ACT_NONE && p.res_mode == RES_NONE && !p.out_f32 && p.SH == 1 && p.SW == 1)) return false;
     static const int min_nk = getenv("OCRVI_DUO_MIN_NK") ? atoi(getenv("OCRVI_DUO_MIN_NK")) : 4;
     if (duo_bn_for(p.Np) == 0 || p.Kp / 32 < min_nk) return false;
     const int resk = p.res_mode == RES_NONE ? 0 : (p.res_f32 ? 1 : 2);
