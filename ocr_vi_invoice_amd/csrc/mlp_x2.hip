@@ -217,29 +217,37 @@ __global__ __launch_bounds__(512 / TB, TB == 2 ? 1 : 2) void mlp_x2_kernel(const
             };
 #pragma unroll
             for (int i = 0; i < P1; ++i) rd1(i, i);
+            // (fenced: left alone hipcc sinks every fragment read to just in front of its first MFMA and waits lgkmcnt(0) for it -- one exposed
+            // LDS round trip per read, 22 cycles per MFMA instead of 17)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 if (ks + P1 < KS) rd1(ks + P1, (ks + P1) % (P1 + 1));
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
                     for (int b = 0; b < TB; ++b)
                         Mma<T>::three(Mma<T>::as_u4v(wr[ks % (P1 + 1)][a][0]), Mma<T>::as_u4v(wr[ks % (P1 + 1)][a][1]), xH[ks][b], xL[ks][b], hacc[a][b]);
                 if (with_gelu) gelu_vals(NV * ks / KS, NV * (ks + 1) / KS, bv);
+                __builtin_amdgcn_sched_barrier(0);
             }
         };
         auto g2 = [&](const char* U2) {   // hprev (chunk k - 1, after its GELU) -> quartets -> GEMM2 into acc2
-            // fragments PFD output blocks ahead (a block is only 3 TB MFMAs, an LDS read under load takes several times that; the four sets take
-            // the registers GEMM1's fragment sets use in its own phase)
-            constexpr int PFD = TB == 2 ? 2 : 3;
-            uint4 w2r[PFD + 1][2];   // [set][hi, lo]
-            auto rd2 = [&](int ab, int set) {
-                const char* r = U2 + (16 * ab + lr) * 128;
-                w2r[set][0] = *(const uint4*)(r + fo0);
-                w2r[set][1] = *(const uint4*)(r + fo1);
+            // Output blocks in groups of GB = 2 / TB (two independent accumulators per group: a block's three products chain on ONE accumulator),
+            // fragments PFG groups ahead, fenced like GEMM1's.
+            constexpr int GB = 2 / TB, NG = NB2 / GB, PFG = 2;
+            uint4 w2r[PFG + 1][GB][2];   // [set][block of the group][hi, lo]
+            auto rd2 = [&](int grp, int set) {
+#pragma unroll
+                for (int i = 0; i < GB; ++i) {
+                    const char* r = U2 + (16 * (grp * GB + i) + lr) * 128;
+                    w2r[set][i][0] = *(const uint4*)(r + fo0);
+                    w2r[set][i][1] = *(const uint4*)(r + fo1);
+                }
             };
 #pragma unroll
-            for (int i = 0; i < PFD; ++i) rd2(i, i);
+            for (int i = 0; i < PFG; ++i) rd2(i, i);
             U hH[TB], hL[TB];
 #pragma unroll
             for (int b = 0; b < TB; ++b) {
@@ -250,12 +258,17 @@ __global__ __launch_bounds__(512 / TB, TB == 2 ? 1 : 2) void mlp_x2_kernel(const
                 const uint4 c0 = Chunk<T>::pack(h0), c1 = Chunk<T>::pack(h1);
                 Mma<T>::regroup(c0, c1, hH[b], hL[b]);
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int ab = 0; ab < NB2; ++ab) {
-                if (ab + PFD < NB2) rd2(ab + PFD, (ab + PFD) % (PFD + 1));
+            for (int grp = 0; grp < NG; ++grp) {
+                if (grp + PFG < NG) rd2(grp + PFG, (grp + PFG) % (PFG + 1));
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int b = 0; b < TB; ++b)
-                    Mma<T>::three(Mma<T>::as_u4v(w2r[ab % (PFD + 1)][0]), Mma<T>::as_u4v(w2r[ab % (PFD + 1)][1]), hH[b], hL[b], acc2[ab][b]);
+                for (int i = 0; i < GB; ++i)
+#pragma unroll
+                    for (int b = 0; b < TB; ++b)
+                        Mma<T>::three(Mma<T>::as_u4v(w2r[grp % (PFG + 1)][i][0]), Mma<T>::as_u4v(w2r[grp % (PFG + 1)][i][1]), hH[b], hL[b], acc2[grp * GB + i][b]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         };
         auto keep = [&]() {
