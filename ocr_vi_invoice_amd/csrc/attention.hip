@@ -138,13 +138,34 @@ __global__ __launch_bounds__(NWV * 64, (IsSplit<T>::value && MAXT <= 16 && NWV =
                 typedef typename Mma<T>::u4v U;
                 U qH, qL;
                 Mma<T>::regroup(qf[0], qf[1], qH, qL);
+                // K fragments (staged as (hi, lo) quartets) one key tile ahead of their MFMAs, fenced: left alone hipcc reads each tile's two
+                // fragments right in front of its three MFMAs and waits lgkmcnt(0) for them -- fifteen exposed LDS round trips per query tile
+                uint4 kq[2][2];
+                auto kread = [&](int t, int set) {
+                    const char* kr = Ksq + (t * 16 + lr) * KROW;
+                    kq[set][0] = *(const uint4*)(kr + o0);
+                    kq[set][1] = *(const uint4*)(kr + o1);
+                };
+                // (the 8-wave builds capped at 128 registers have no room for the second fragment set at 16 key tiles or with key masks: they
+                // read in place as before)
+                constexpr bool PRE = !(MAXT <= 16 && NWV == 8 && (MASK || MAXT == 16));
+                if constexpr (PRE) {
+                    kread(0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
                 for (int t = 0; t < MAXT; ++t) {
+                    if constexpr (PRE) {
+                        if (t + 1 < MAXT) kread(t + 1, (t + 1) & 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else {
+                        kread(t, t & 1);
+                    }
                     acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    const char* kr = Ksq + (t * 16 + lr) * KROW;
-                    const uint4 k0 = *(const uint4*)(kr + o0), k1 = *(const uint4*)(kr + o1);     // staged as (hi, lo) quartets
+                    const uint4 k0 = kq[t & 1][0], k1 = kq[t & 1][1];
                     const U kH = {k0.x, k0.y, k0.z, k0.w}, kL = {k1.x, k1.y, k1.z, k1.w};
                     Mma<T>::three(kH, kL, qH, qL, acc[t]);
+                    if constexpr (PRE) __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
 #pragma unroll
@@ -223,8 +244,30 @@ __global__ __launch_bounds__(NWV * 64, (IsSplit<T>::value && MAXT <= 16 && NWV =
         f32x4 o[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
         f32x4 osum = (f32x4){0.f, 0.f, 0.f, 0.f};  // 16-bit modes: row sums by MFMA against a ones fragment
         if constexpr (IsSplit<T>::value) {
+            // V^T fragments of step s + 1 are requested before step s's split + MFMAs (fenced, like the K fragments above)
+            constexpr int NS = (MAXT + 1) / 2;
+            uint4 vq[2][2][2];   // [set][dt][hi, lo]
+            auto vread = [&](int s, int set) {
 #pragma unroll
-            for (int s = 0; s < (MAXT + 1) / 2; ++s) {       // 32 keys per step: the P chunks of tiles 2s and 2s + 1 form one (hi, lo) quartet pair
+                for (int dt = 0; dt < 2; ++dt) {
+                    const char* vr = Vtq + (dt * 16 + lr) * VS + 128 * s + 32 * g;   // the step's keys of head-dim row 16 dt + lr, staged as (hi, lo) quartets
+                    vq[set][dt][0] = *(const uint4*)vr;
+                    vq[set][dt][1] = *(const uint4*)(vr + 16);
+                }
+            };
+            constexpr bool PRE = !(MAXT <= 16 && NWV == 8 && (MASK || MAXT == 16));   // (as for the K fragments)
+            if constexpr (PRE) {
+                vread(0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {       // 32 keys per step: the P chunks of tiles 2s and 2s + 1 form one (hi, lo) quartet pair
+                if constexpr (PRE) {
+                    if (s + 1 < NS) vread(s + 1, (s + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    vread(s, s & 1);
+                }
                 typedef typename Mma<T>::u4v U;
                 // the (hi, lo) quartets of P straight from the accumulators, two scores per conversion (what Chunk<T>::pack + regroup produce,
                 // bit for bit: hi = RNE(p), lo = RNE(p - hi)): keys 32 s + 4 g .. + 3 of query lr, then 32 s + 16 + 4 g .. + 3 (nothing past the last tile)
@@ -239,11 +282,11 @@ __global__ __launch_bounds__(NWV * 64, (IsSplit<T>::value && MAXT <= 16 && NWV =
                 const U pH = {h0, h1, h2, h3}, pL = {l0, l1, l2, l3};
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
-                    const char* vr = Vtq + (dt * 16 + lr) * VS + 128 * s + 32 * g;   // the same keys of head-dim row 16 dt + lr, staged as (hi, lo) quartets
-                    const uint4 v0 = *(const uint4*)vr, v1 = *(const uint4*)(vr + 16);
+                    const uint4 v0 = vq[s & 1][dt][0], v1 = vq[s & 1][dt][1];
                     const U vH = {v0.x, v0.y, v0.z, v0.w}, vL = {v1.x, v1.y, v1.z, v1.w};
                     Mma<T>::three(vH, vL, pH, pL, o[dt]);
                 }
+                if constexpr (PRE) __builtin_amdgcn_sched_barrier(0);
             }
         } else if constexpr (sizeof(T) == 4) {
 #pragma unroll

@@ -301,13 +301,9 @@ template <> struct Mma<f16x2_t> {   // operands are chunks [4 hi | 4 lo]: hh + l
         H = (u4v){c0.x, c0.y, c1.x, c1.y};
         L = (u4v){c0.z, c0.w, c1.z, c1.w};
     }
-    // the same regrouping IN PLACE: two v_swap_b32 exchange c0's lo pair with c1's hi pair, after which c0's registers hold H and c1's hold L
-    // -- no copies and no extra registers (as plain C++ the regrouping costs four moves into eight new registers; the kernels at the
-    // 256-register limit cannot afford those while the raw chunks are still live)
-    __device__ static inline void regroup_swap(uint4& c0, uint4& c1) {
-        asm("v_swap_b32 %0, %1" : "+v"(c0.z), "+v"(c1.x));
-        asm("v_swap_b32 %0, %1" : "+v"(c0.w), "+v"(c1.y));
-    }
+    // (Round 4 had an in-place form of this -- two inline-asm v_swap_b32 -- to save the copies' registers.  Pinned directly in front of the MFMAs
+    // that read the swapped registers it produced wrong results in conv_gemm (hipcc places the wait states between a vector write and the matrix
+    // instruction that reads it only for instructions it can see, as with the attention kernel's inline-asm conversions behind v_exp_f32): removed.)
     __device__ static inline u4v as_u4v(const uint4& c) { return (u4v){c.x, c.y, c.z, c.w}; }
     __device__ static inline void three(const u4v& wH, const u4v& wL, const u4v& xH, const u4v& xL, f32x4& c) {
         c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wL), __builtin_bit_cast(f16x8, xH), c, 0, 0, 0);

@@ -471,22 +471,32 @@ __global__ __launch_bounds__(256, (ConvOccT<T, AMODE, BM, BN>::value)) void conv
             // -- they are not bound by the matrix pipe -- so they stay as they are)
             if constexpr (IsSplit<T>::value && BN >= 128) {
                 typedef typename Mma<T>::u4v U;
-                uint4 xr[MI][2];   // regrouped IN PLACE (two v_swap_b32 per fragment pair: no copies, no second register set)
+                U xH[MI], xL[MI];
 #pragma unroll
                 for (int b = 0; b < MI; ++b) {
                     const char* r = As + (wm * TM + b * 16 + lr) * 128;
-                    xr[b][0] = *(const uint4*)(r + fo0);
-                    xr[b][1] = *(const uint4*)(r + fo1);
-                    Mma<T>::regroup_swap(xr[b][0], xr[b][1]);
+                    Mma<T>::regroup(*(const uint4*)(r + fo0), *(const uint4*)(r + fo1), xH[b], xL[b]);
                 }
+                // weight fragments one row ahead of their MFMAs, fenced (left alone hipcc reads a row's two fragments right in front of its MFMAs
+                // and waits lgkmcnt(0) for them: an exposed LDS round trip per row, four per K-step)
+                uint4 wq[2][2];
+                auto wread = [&](int a, int set) {
+                    const char* r = Bs + (wn * TN + a * 16 + lr) * 128;
+                    wq[set][0] = *(const uint4*)(r + fo0);
+                    wq[set][1] = *(const uint4*)(r + fo1);
+                };
+                wread(0, 0);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int a = 0; a < NI; ++a) {
-                    const char* r = Bs + (wn * TN + a * 16 + lr) * 128;
-                    uint4 w0 = *(const uint4*)(r + fo0), w1 = *(const uint4*)(r + fo1);
-                    Mma<T>::regroup_swap(w0, w1);
+                    if (a + 1 < NI) wread(a + 1, (a + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    U wH, wL;    // (copies, not the in-place swap: pinned right in front of the MFMAs an inline-asm v_swap_b32 fed them stale registers
+                                 // -- hipcc places wait states only for instructions it can see; tests/test_gpu_kernels.py::test_conv_kernel[case6-f16x2])
+                    Mma<T>::regroup(wq[a & 1][0], wq[a & 1][1], wH, wL);
 #pragma unroll
-                    for (int b = 0; b < MI; ++b)
-                        Mma<T>::three(Mma<T>::as_u4v(w0), Mma<T>::as_u4v(w1), Mma<T>::as_u4v(xr[b][0]), Mma<T>::as_u4v(xr[b][1]), acc[a][b]);
+                    for (int b = 0; b < MI; ++b) Mma<T>::three(wH, wL, xH[b], xL[b], acc[a][b]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             } else
 #pragma unroll

@@ -601,10 +601,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gemm_ring_kernel(const ConvPa
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 U xH[MI], xL[MI];
+#pragma unroll
+                for (int b = 0; b < MI; ++b) Mma<T>::regroup(xr[b][0], xr[b][1], xH[b], xL[b]);
                 // weight rows one row = 12 MFMAs ahead, requested BEFORE the row's MFMAs (fenced: hipcc otherwise sinks the reads to a few MFMAs
-                // before their use and waits on them at once).  The pixel fragments are regrouped where the first row uses them, block by block
-                // (fenced): all eight waves request their 10 reads at once behind the step's barrier, and the first MFMA should wait for its own
-                // four (weight row 0, pixel block 0), not for the wave's last one
+                // before their use and waits on them at once).  (Round 4 tried regrouping each pixel fragment in place -- two inline-asm v_swap_b32 --
+                // right where weight row 0 first uses it: neutral in time, and an inline-asm write directly in front of the MFMA that reads it is
+                // outside hipcc's wait-state bookkeeping -- the same construction fed conv_gemm stale registers.  Reverted.)
 #pragma unroll
                 for (int a = 0; a < NI; ++a) {
                     U wH, wL;
@@ -612,17 +614,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gemm_ring_kernel(const ConvPa
                     if (a + 1 < NI) wread(a + 1, n0, n1);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int b = 0; b < MI; ++b) {
-                        if (a == 0) {
-                            Mma<T>::regroup_swap(xr[b][0], xr[b][1]);
-                            xH[b] = Mma<T>::as_u4v(xr[b][0]);
-                            xL[b] = Mma<T>::as_u4v(xr[b][1]);
-                            Mma<T>::three(wH, wL, xH[b], xL[b], acc[a][b]);
-                            __builtin_amdgcn_sched_barrier(0);
-                        } else {
-                            Mma<T>::three(wH, wL, xH[b], xL[b], acc[a][b]);
-                        }
-                    }
+                    for (int b = 0; b < MI; ++b) Mma<T>::three(wH, wL, xH[b], xL[b], acc[a][b]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
