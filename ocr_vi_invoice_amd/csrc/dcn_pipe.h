@@ -310,6 +310,13 @@ __global__ __launch_bounds__(512, 2) void dcn_pipe_kernel(const ConvParams p) {
         for (int b = 0; b < 2; ++b) {
             const int m = pixel_of(wm * 32 + 16 * b + lr);
             if constexpr (PERM) {
+                float4 bvs[NI / 2][2];   // (bias of all blocks first, clamped addresses, outside the per-block branches: see below)
+#pragma unroll
+                for (int hh = 0; hh < NI / 2; ++hh) {
+                    const int n = min(n0 + wn * (BN / 2) + 32 * hh + 8 * g, p.N_g - 8);
+                    bvs[hh][0] = p.bias ? *(const float4*)(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    bvs[hh][1] = p.bias ? *(const float4*)(p.bias + n + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
 #pragma unroll
                 for (int hh = 0; hh < NI / 2; ++hh) {
                     const int n = n0 + wn * (BN / 2) + 32 * hh + 8 * g;
@@ -320,9 +327,9 @@ __global__ __launch_bounds__(512, 2) void dcn_pipe_kernel(const ConvParams p) {
                             v[r] = acc[2 * hh][b][r];
                             v[4 + r] = acc[2 * hh + 1][b][r];
                         }
-                        if (p.bias) {
-#pragma unroll
-                            for (int r = 0; r < 8; ++r) v[r] += p.bias[n + r];
+                        {
+                            v[0] += bvs[hh][0].x; v[1] += bvs[hh][0].y; v[2] += bvs[hh][0].z; v[3] += bvs[hh][0].w;
+                            v[4] += bvs[hh][1].x; v[5] += bvs[hh][1].y; v[6] += bvs[hh][1].z; v[7] += bvs[hh][1].w;
                         }
                         if (p.act == ACT_RELU) {
 #pragma unroll
@@ -332,15 +339,22 @@ __global__ __launch_bounds__(512, 2) void dcn_pipe_kernel(const ConvParams p) {
                     }
                 }
             } else {
+                // (the bias of all NI blocks first, from clamped addresses and outside the per-block branches: inside them every block's load got
+                // its own vmcnt(0) in front of its store)
+                float4 bvs[NI];
+#pragma unroll
+                for (int a = 0; a < NI; ++a) {
+                    const int n = min(n0 + wn * (BN / 2) + 16 * a + 4 * g, p.N_g - 4);
+                    bvs[a] = p.bias ? *(const float4*)(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
 #pragma unroll
                 for (int a = 0; a < NI; ++a) {
                     const int n = n0 + wn * (BN / 2) + 16 * a + 4 * g;
                     if (m >= 0 && n < p.N_g) {
                         float v[4] = {unscale<T>(acc[a][b][0], p.wscale), unscale<T>(acc[a][b][1], p.wscale), unscale<T>(acc[a][b][2], p.wscale),
                                       unscale<T>(acc[a][b][3], p.wscale)};
-                        if (p.bias) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] += p.bias[n + r];
+                        {
+                            v[0] += bvs[a].x; v[1] += bvs[a].y; v[2] += bvs[a].z; v[3] += bvs[a].w;
                         }
                         if (p.act == ACT_RELU) {
 #pragma unroll
